@@ -1,0 +1,188 @@
+// gemm_f32.hip -- exact-fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the cuBLAS calls under tf.layers.dense / tf.tensordot / CudnnGRU input projections
+// of the reference graph (src/model.py:120-121,149-156,160-168) and their autodiff duals.
+//
+// Block tile 128x128, BK = 32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles.
+// Global -> registers -> LDS staging with the next K-tile's loads in flight during the MFMAs;
+// 2-3 workgroups per CU overlap each other's staging phases.
+//
+// MFMA operand map (lane l, h = l>>5):  A[i = l&31][k = h],  B[k = h][j = l&31].
+// Within a 32-deep K tile, MFMA step j (0..15) of lane-half h consumes k = 8*(j>>2) + 4*h + (j&3):
+// a k-contiguous operand row then feeds four consecutive steps from ONE ds_read_b128.
+#include "kernels.h"
+
+namespace avae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 4;     // k-contiguous tile row stride (floats): conflict-free b128 reads
+constexpr int TILE_FLOATS = BM * LDK;   // >= BK*BM
+
+__device__ __forceinline__ int kmap(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// stage one operand tile (128 x 32) global -> 4 float4 registers per thread
+template <bool XC>   // XC: x(m or n)-contiguous storage [k][x];  else k-contiguous [x][k]
+__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ P, int ld,
+                                          int x0, int X, int k0, int K1, int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        int f = tid + 256 * rep;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (XC) {
+            int k = k0 + (f >> 5), x = x0 + ((f & 31) << 2);
+            if (k < K1 && x < X) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);
+        } else {
+            int x = x0 + (f >> 3), k = k0 + ((f & 7) << 2);
+            if (x < X && k < K1) v = *reinterpret_cast<const float4*>(P + (size_t)x * ld + k);
+        }
+        r[rep] = v;
+    }
+}
+
+template <bool XC>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        int f = tid + 256 * rep;
+        if (XC) *reinterpret_cast<float4*>(s + (f >> 5) * BM + ((f & 31) << 2)) = r[rep];
+        else    *reinterpret_cast<float4*>(s + (f >> 3) * LDK + ((f & 7) << 2)) = r[rep];
+    }
+}
+
+template <bool A_MC, bool B_NC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+    float* As = smem;
+    float* Bs = smem + TILE_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int M = g.M, K = g.K;
+    if (g.dyn_kind == 1) M = min(M, *g.dyn);
+    if (g.dyn_kind == 2) K = min(K, *g.dyn);
+
+    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give each
+    // XCD a contiguous run of tiles; tiles advance along N fastest so a run shares A panels.
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+
+    // K range of this split
+    int kb = 0, ke = K;
+    if (g.split_k > 1) {
+        int ktiles = (K + BK - 1) / BK;
+        int per = (ktiles + g.split_k - 1) / g.split_k;
+        kb = blockIdx.z * per * BK;
+        ke = min(K, kb + per * BK);
+        if (kb >= ke) return;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    load_tile<A_MC>(ra, g.A, g.lda, m0, M, kb, ke, tid);
+    load_tile<B_NC>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        store_tile<A_MC>(As, ra, tid);
+        store_tile<B_NC>(Bs, rb, tid);
+        __syncthreads();
+        if (k0 + BK < ke) {
+            load_tile<A_MC>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
+            load_tile<B_NC>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (A_MC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[t][e] = As[(8 * q + 4 * h + e) * BM + 64 * wm + 32 * t + l31];
+                } else {
+                    float4 v = *reinterpret_cast<const float4*>(As + (64 * wm + 32 * t + l31) * LDK + 8 * q + 4 * h);
+                    a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
+                }
+                if (B_NC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[t][e] = Bs[(8 * q + 4 * h + e) * BN + 64 * wn + 32 * t + l31];
+                } else {
+                    float4 v = *reinterpret_cast<const float4*>(Bs + (64 * wn + 32 * t + l31) * LDK + 8 * q + 4 * h);
+                    b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool atomic = g.split_k > 1;
+    const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int col = n0 + 64 * wn + 32 * j + l31;
+        if (col >= g.N) continue;
+        float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
+{
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if ((g.lda | g.ldb) & 3) return hipErrorInvalidValue;
+    if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) return hipErrorInvalidValue;
+    // contiguous extents must be multiples of 4 (float4 staging)
+    if (!a_mc && (g.K & 3)) return hipErrorInvalidValue;
+    if (a_mc && (g.M & 3)) return hipErrorInvalidValue;
+    if (!b_nc && (g.K & 3)) return hipErrorInvalidValue;
+    if (b_nc && (g.N & 3)) return hipErrorInvalidValue;
+    int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
+    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else                     hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+
+}  // namespace avae

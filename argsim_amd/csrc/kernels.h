@@ -1,0 +1,127 @@
+// kernels.h -- internal launch interface of the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace avae {
+
+// ---------------------------------------------------------------- GEMM (gemm_f32.hip)
+// C[M,N] = alpha * op(A) * op(B) (+ bias[n]) (+ C if accumulate), exact fp32 on
+// v_mfma_f32_32x32x2_f32.  Row-major storage with leading dimensions:
+//   a_mc == false : A[m*lda + k]   (k contiguous)     a_mc == true : A[k*lda + m]
+//   b_nc == false : B[n*ldb + k]   (k contiguous)     b_nc == true : B[k*ldb + n]
+// The contiguous dimension and every leading dimension must be a multiple of 4 floats and
+// every base pointer 16-byte aligned.  M/N/K edges are predicated (zero filled).
+// dyn (optional, device): the real row count when it is only known on the device:
+//   dyn_kind 1 -> M_eff = min(M, *dyn) (row tiles beyond it exit),  2 -> K_eff = min(K, *dyn).
+// split_k > 1: grid.z slices of K, combined with float atomics INTO C (C must hold the value to
+// accumulate onto, e.g. zeros); bias is added by slice 0.
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    float alpha;
+    int accumulate;      // C += ...
+    int split_k;
+    const int* dyn; int dyn_kind;
+};
+hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
+
+// ---------------------------------------------------------------- GRU (gru.hip)
+// Gate-interleaved layout ("G16"): the 3D gate rows of W, R, bW, bR and the 3D columns of
+// gi / dgi / dgh are stored in the order  c' = ht*48 + gate*16 + u   (ht = unit/16, u = unit%16,
+// gate: 0=r 1=u 2=n) so that the 48 values one workgroup owns are contiguous.
+constexpr int kMaxGruJobs = 3;
+struct GruJob {
+    const float* gi;      // + job column offset; row (pos*B + b) at gi + (pos*B+b)*ldg
+    const float* R;       // (3D, D) G16 rows
+    const float* bR;      // (3D) G16
+    const float* h0;      // (B, D) or nullptr (zeros)
+    float* hs;            // output, row (pos*B+b) at hs + (pos*B+b)*ldh (+ column offset applied)
+    float* sv;            // saved r,u,n,hn: (S,B,HT,4,16) or nullptr
+    float* hp;            // saved h_prev (S,B,D) or nullptr
+    int reverse;          // 1: time index map of tf.reverse_sequence (needs lens)
+    // backward only
+    const float* dh_out;  // grad wrt hs (same indexing as hs: ldh) or nullptr
+    float* dgi;           // (S,B,ldg) G16 columns (+ job offset)
+    float* dgh;           // (S,B,ldg)
+    float* dh0;           // (B,D) or nullptr
+    float* carry;         // (B,D) scratch: dH_{p+1} * u_{p+1}
+};
+struct GruArgs {
+    GruJob job[kMaxGruJobs];
+    int njobs, S, B, D, ldg, ldh;
+    const int* lens;      // (B) or nullptr
+    int G;                // batch groups per job
+    int rows_per_group;   // multiple of 16
+    int p_begin, p_end;   // steps [p_begin, p_end) of this launch
+    unsigned* counters;   // njobs*G words, zeroed by the launcher
+    int* err;             // device error word (set on spin timeout)
+};
+hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
+hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
+bool gru_dim_supported(int D);
+
+// ---------------------------------------------------------------- small kernels (ops.hip)
+struct PrepArgs {
+    const int32_t* src; const int32_t* tgt;   // (B,Ss),(B,St) row-major
+    int B, Ss, St, eos, bos;
+    int train; float keepwd; uint64_t seed; const uint8_t* keep_mask;  // (St,B)
+    int32_t* src_tm;    // (Ss,B)
+    int32_t* lens_src;  // (B)
+    int32_t* lens_tgt;  // (B)
+    int32_t* lead;      // (St+1,B)
+    int32_t* gold;      // (St+1,B)
+    int32_t* rank;      // (St+1,B) compact row of (t,b) or -1
+    int32_t* cidx;      // (N) flat (t*B+b) of compact row
+    int32_t* ntok;      // [0]=N
+};
+hipError_t prep_ids(hipStream_t st, const PrepArgs& p);
+
+hipError_t embed_gather(hipStream_t st, const float* E, const int32_t* ids, float* out, int n, int D, int V);
+hipError_t embed_scatter_add(hipStream_t st, float* dE, const int32_t* ids, const float* dout, int n, int D, int V);
+// dst[i,:] = src[idx[i],:] for i < *n_dev
+hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);
+// dst[r,:] = rank[r] >= 0 ? src[rank[r],:] : 0   for r < rows
+hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D);
+// h[b,:] = hs[(len_b-1)*B + b, :]  (model.py:135)
+hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W);
+// dhs = 0 everywhere except dhs[(len_b-1)*B+b,:] = dh[b,:]
+hipError_t pick_last_bwd(hipStream_t st, float* dhs, const float* dh, const int32_t* lens, int S, int B, int W);
+
+// z = mu (+ exp(lv/2)*eps when train; eps from eps_in or the counter RNG, echoed to eps_out);
+// kld[i] = 0.5(mu^2 + e^lv - lv - 1); acc[0] += sum max(kld, free_bits)
+hipError_t latent_fwd(hipStream_t st, const float* mu, const float* lv, const float* eps_in, float* eps_out, float* z,
+                      float* kld, int n, int train, uint64_t seed, float free_bits, float* acc);
+// dmu = dz + c*mu ; dlv = dz*eps*0.5*exp(lv/2) + c*0.5*(exp(lv)-1), c = anneal/(Bg*R) (free-bits gated)
+hipError_t latent_bwd(hipStream_t st, const float* dz, const float* mu, const float* lv, const float* eps_used,
+                      float* dmu, float* dlv, int B, int R, float coef, float free_bits);
+
+struct CeArgs {
+    float* logits;            // (N,V) in: logits, out (if dlogits): (softmax - onehot) * scale
+    const int32_t* gold;      // (T,B) flat
+    const int32_t* cidx;      // (N) -> flat (t,b)
+    const int32_t* n_dev;     // real N
+    int n_max, V;
+    int write_grad; float inv_n;   // scale; <= 0 -> 1 / *n_dev
+    float* loss_samp; float* errt_samp; int32_t* pred;   // (N) optional
+    float* loss_acc;          // [0] += sum loss_samp
+};
+hipError_t softmax_ce(hipStream_t st, const CeArgs& a);
+// pred[i] = argmax_j logits[i, j]  (first max), rows < n
+hipError_t argmax_rows(hipStream_t st, const float* logits, int32_t* pred, int n, int V);
+
+// out[n] (+)= sum_m X[m, n]
+hipError_t colsum(hipStream_t st, const float* X, int M, int N, int ldx, float* out, const int32_t* m_dev);
+hipError_t add3(hipStream_t st, float* out, const float* a, const float* b, const float* c, int64_t n);
+
+struct AdamArgs { float* p; const float* g; float* m; float* v; int64_t n; float lr_t, b1, b2, eps; };
+hipError_t adam_tf(hipStream_t st, const AdamArgs& a);
+
+// natural <-> G16 row permutation of a (3D, cols) matrix (cols = 1 for biases)
+hipError_t g16_permute(hipStream_t st, float* dst, const float* src, int D, int cols, bool to_g16);
+
+// losses[0..2] = loss_gen, loss_kld, loss from accumulators
+hipError_t finalize_losses(hipStream_t st, float* losses, const float* acc, const int32_t* n_dev,
+                           float n_override, float inv_br, float anneal);
+
+}  // namespace avae

@@ -1,0 +1,809 @@
+// model.cpp -- host orchestration of the VAE step on one MI355X and the C ABI (include/argsim_vae.h).
+//
+// Restates the dataflow of reference src/model.py:75-189 as a fixed sequence of kernel launches
+// on one HIP stream: prep -> gather -> 3x(bidirectional GRU) -> latent -> 3x GRU decoder ->
+// out affine -> tied logits -> softmax-CE, then the hand-derived backward in reverse order and
+// TF-style Adam.  No tracing compiler, no autograd: every buffer lives in one workspace laid out
+// by a bump allocator.
+#include "../../include/argsim_vae.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace avae;
+
+namespace {
+
+struct ParamEntry {
+    std::string name;
+    int64_t offset;
+    int ndim;
+    int64_t shape[4];
+    int g16;          // rows are stored gate-interleaved (GRU W/R/bW/bR)
+    int bucket;
+};
+
+struct GruP { int64_t W, R, bW, bR; };     // offsets into the flat state
+
+static std::string g_create_err;
+
+}  // namespace
+
+struct avae_ctx {
+    avae_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<ParamEntry> params;
+    int64_t numel = 0;
+    std::vector<std::pair<int64_t, int64_t>> buckets;    // (offset, count) in completion order
+    float *P = nullptr, *G = nullptr, *M = nullptr, *Vv = nullptr;
+    int64_t step = 0;
+    avae_grad_hook hook = nullptr; void* hook_user = nullptr;
+    int persistent = 1;
+    // offsets
+    int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
+    std::vector<GruP> enc;     // per layer: W = [fwd;bwd] (6D,In), R = [fwd;bwd], bW (6D), bR (6D)
+    std::vector<GruP> dec;
+    // small persistent device state
+    float* losses = nullptr;   // [3]
+    float* acc = nullptr;      // [2] sum loss_gen_samp, sum kld
+    int* errw = nullptr;       // GRU spin time-out word
+    unsigned* counters = nullptr;
+    float* scratch = nullptr;  // staging for get/set tensor
+    int64_t scratch_n = 0;
+    // workspace
+    char* ws = nullptr; size_t ws_cap = 0;
+    // last forward geometry
+    int B = 0, Ss = 0, St = 0;
+};
+
+namespace {
+
+#define AV_CHECK(expr)                                                                              \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                            \
+        char b_[512]; snprintf(b_, sizeof b_, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+        h->err = b_; return 1; } } while (0)
+#define AV_TRY(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
+
+int fail(avae_ctx* h, const std::string& m) { h->err = m; return 1; }
+
+// -------------------------------------------------------------------------------- workspace
+struct Ws {
+    // ints
+    int32_t *src_tm, *lens_src, *lens_tgt, *lead, *gold, *rank, *cidx, *ntok, *pred;
+    // forward
+    float *emb_src, *emb_tgt;
+    std::vector<float*> e_gi, e_hs, e_sv[2], e_hp[2];
+    std::vector<float*> d_gi, d_hd, d_sv, d_hp;
+    float *hpick, *mu, *lv, *z, *eps, *kld, *h0;
+    float *hc, *ho, *logits;
+    float *loss_samp, *errt_samp;
+    // backward
+    float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
+    float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
+};
+
+struct Bump {
+    char* base; size_t off = 0;
+    template <class T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
+{
+    const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
+    const size_t T = St + 1, rs = (size_t)Ss * B, rt = T * B;
+    w.src_tm = b.take<int32_t>(rs); w.lens_src = b.take<int32_t>(B); w.lens_tgt = b.take<int32_t>(B);
+    w.lead = b.take<int32_t>(rt); w.gold = b.take<int32_t>(rt); w.rank = b.take<int32_t>(rt);
+    w.cidx = b.take<int32_t>(rt); w.ntok = b.take<int32_t>(4); w.pred = b.take<int32_t>(rt);
+    w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
+    w.e_gi.resize(L); w.e_hs.resize(L);
+    for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
+    w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
+    for (int i = 0; i < L; ++i) {
+        w.e_gi[i] = b.take<float>(rs * 6 * D);
+        w.e_hs[i] = b.take<float>(rs * 2 * D);
+        for (int d = 0; d < 2; ++d) {
+            w.e_sv[d][i] = train ? b.take<float>(rs * 4 * D) : nullptr;
+            w.e_hp[d][i] = train ? b.take<float>(rs * D) : nullptr;
+        }
+    }
+    for (int i = 0; i < L; ++i) {
+        w.d_gi[i] = b.take<float>(rt * 3 * D);
+        w.d_hd[i] = b.take<float>(rt * D);
+        w.d_sv[i] = train ? b.take<float>(rt * 4 * D) : nullptr;
+        w.d_hp[i] = train ? b.take<float>(rt * D) : nullptr;
+    }
+    w.hpick = b.take<float>((size_t)B * 2 * D);
+    w.mu = b.take<float>((size_t)B * R); w.lv = b.take<float>((size_t)B * R); w.z = b.take<float>((size_t)B * R);
+    w.eps = b.take<float>((size_t)B * R); w.kld = b.take<float>((size_t)B * R);
+    w.h0 = b.take<float>((size_t)B * D);
+    w.hc = b.take<float>(rt * D); w.ho = b.take<float>(rt * D); w.logits = b.take<float>(rt * V);
+    w.loss_samp = b.take<float>(rt); w.errt_samp = b.take<float>(rt);
+    if (train) {
+        w.dho = b.take<float>(rt * D); w.dhc = b.take<float>(rt * D);
+        w.dhd[0] = b.take<float>(rt * D); w.dhd[1] = b.take<float>(rt * D);
+        w.dgi_d = b.take<float>(rt * 3 * D); w.dgh_d = b.take<float>(rt * 3 * D);
+        w.dh0 = b.take<float>((size_t)L * B * D); w.carry = b.take<float>((size_t)3 * B * D);
+        w.dh0sum = b.take<float>((size_t)B * D);
+        w.dz = b.take<float>((size_t)B * R); w.dmu = b.take<float>((size_t)B * R); w.dlv = b.take<float>((size_t)B * R);
+        w.dhpick = b.take<float>((size_t)B * 2 * D);
+        w.dhs[0] = b.take<float>(rs * 2 * D); w.dhs[1] = b.take<float>(rs * 2 * D);
+        w.dgi_e = b.take<float>(rs * 6 * D); w.dgh_e = b.take<float>(rs * 6 * D);
+        w.demb_src = b.take<float>(rs * D); w.demb_tgt = b.take<float>(rt * D);
+    }
+}
+
+int get_ws(avae_ctx* h, Ws& w, int B, int Ss, int St, bool train)
+{
+    Bump probe{nullptr};
+    layout(h, probe, w, B, Ss, St, train);
+    size_t need = probe.off + 4096;
+    if (need > h->ws_cap) {
+        AV_CHECK(hipStreamSynchronize(h->stream));
+        if (h->ws) AV_CHECK(hipFree(h->ws));
+        h->ws = nullptr; h->ws_cap = 0;
+        size_t cap = need + need / 8;
+        AV_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), cap));
+        h->ws_cap = cap;
+    }
+    Bump real{h->ws};
+    layout(h, real, w, B, Ss, St, train);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------- helpers
+int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
+         int M, int N, int K, float alpha = 1.f, const float* bias = nullptr, int accumulate = 0, int split_k = 1,
+         const int* dyn = nullptr, int dyn_kind = 0)
+{
+    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind};
+    AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
+    return 0;
+}
+// K-split so that a weight-gradient GEMM (few output tiles, very long K) fills the 256 CUs
+int grad_split(int M, int N, int K)
+{
+    int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles >= 192) return 1;
+    int s = (512 + tiles - 1) / tiles;
+    int kmax = K / 256; if (kmax < 1) kmax = 1;
+    if (s > kmax) s = kmax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+// dW (M x N) += A^T B over K rows; A [k][m] lda, B [k][n] ldb.  grads are zero-filled beforehand.
+int gemm_tn_grad(avae_ctx* h, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                 float alpha = 1.f, const int* dynk = nullptr)
+{
+    int s = grad_split(M, N, K);
+    return gemm(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0);
+}
+
+void gru_geometry(int D, int njobs, int B, int* G, int* rpg)
+{
+    int HT = D / 16;
+    int gmax = 512 / (njobs * HT); if (gmax < 1) gmax = 1; if (gmax > 16) gmax = 16;
+    int g = (B + 15) / 16; if (g > gmax) g = gmax; if (g < 1) g = 1;
+    int r = (B + g - 1) / g; r = (r + 15) / 16 * 16;
+    g = (B + r - 1) / r;
+    *G = g; *rpg = r;
+}
+
+struct Sched { float keepwd, anneal, lr; };
+Sched schedule(const avae_ctx* h)
+{
+    // src/model.py:77-80, float32 like the TF graph
+    float rate = h->cfg.accelerate * (float)h->step;
+    Sched s;
+    s.keepwd = 1.f / (1.f + expf(-rate));
+    s.anneal = tanhf(rate);
+    s.lr = h->cfg.learn_rate / (sqrtf(rate) + 1.f);
+    return s;
+}
+
+// -------------------------------------------------------------------------------- forward pieces
+int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
+{
+    const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
+    const int rs = Ss * B;
+    AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.src_tm, w.emb_src, rs, D, V));
+    const float* x = w.emb_src; int In = D;
+    for (int i = 0; i < L; ++i) {
+        const GruP& p = h->enc[i];
+        AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, 6 * D, In, 1.f, h->P + p.bW));
+        GruArgs a{};
+        a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
+        gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw;
+        for (int d = 0; d < 2; ++d) {
+            GruJob& j = a.job[d];
+            j.gi = w.e_gi[i] + d * 3 * D;
+            j.R = h->P + p.R + (int64_t)d * 3 * D * D;
+            j.bR = h->P + p.bR + d * 3 * D;
+            j.h0 = nullptr;
+            j.hs = w.e_hs[i] + d * D;
+            j.sv = save ? w.e_sv[d][i] : nullptr;
+            j.hp = save ? w.e_hp[d][i] : nullptr;
+            j.reverse = d;
+        }
+        AV_CHECK(gru_forward(h->stream, a, h->persistent != 0));
+        x = w.e_hs[i]; In = 2 * D;
+    }
+    AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D));
+    return 0;
+}
+
+int run_latent(avae_ctx* h, Ws& w, int B, bool train, uint64_t seed, const float* eps)
+{
+    const int D = h->cfg.dim_emb, R = h->cfg.dim_rep;
+    AV_TRY(gemm(h, false, true, w.hpick, 2 * D, h->P + h->oWmu, R, w.mu, R, B, R, 2 * D, 1.f, h->P + h->oBmu));
+    AV_TRY(gemm(h, false, true, w.hpick, 2 * D, h->P + h->oWlv, R, w.lv, R, B, R, 2 * D, 1.f, h->P + h->oBlv));
+    AV_CHECK(latent_fwd(h->stream, w.mu, w.lv, eps, w.eps, w.z, w.kld, B * R, train ? 1 : 0, seed, h->cfg.free_bits, h->acc + 1));
+    return 0;
+}
+
+// decoder GRU stack over T steps from per-layer initial states (state stride: layer * B * D; 0 = shared h0)
+int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int64_t state_stride, bool save)
+{
+    const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
+    const int rt = T * B;
+    const float* x = w.emb_tgt;
+    for (int i = 0; i < L; ++i) {
+        const GruP& p = h->dec[i];
+        AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
+        GruArgs a{};
+        a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
+        gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw;
+        GruJob& j = a.job[0];
+        j.gi = w.d_gi[i]; j.R = h->P + p.R; j.bR = h->P + p.bR;
+        j.h0 = state_in + state_stride * i;
+        j.hs = w.d_hd[i];
+        j.sv = save ? w.d_sv[i] : nullptr;
+        j.hp = save ? w.d_hp[i] : nullptr;
+        j.reverse = 0;
+        AV_CHECK(gru_forward(h->stream, a, h->persistent != 0));
+        x = w.d_hd[i];
+    }
+    return 0;
+}
+
+int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, int Ss, int St, bool train,
+            uint64_t seed, const uint8_t* keep_mask, const float* eps, float inv_n)
+{
+    const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
+    const int T = St + 1, rt = T * B;
+    Sched sc = schedule(h);
+    AV_CHECK(hipMemsetAsync(h->acc, 0, 2 * sizeof(float), h->stream));
+    PrepArgs p{};
+    p.src = src; p.tgt = tgt; p.B = B; p.Ss = Ss; p.St = St; p.eos = h->cfg.eos; p.bos = h->cfg.bos;
+    p.train = train ? 1 : 0; p.keepwd = sc.keepwd; p.seed = seed; p.keep_mask = keep_mask;
+    p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
+    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok;
+    AV_CHECK(prep_ids(h->stream, p));
+    AV_TRY(run_encoder(h, w, B, Ss, train));
+    AV_TRY(run_latent(h, w, B, train, seed, eps));
+    AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
+    AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.lead, w.emb_tgt, rt, D, V));
+    AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train));
+    AV_CHECK(rows_gather(h->stream, w.hc, w.d_hd[L - 1], w.cidx, w.ntok, rt, D));
+    AV_TRY(gemm(h, false, true, w.hc, D, h->P + h->oKout, D, w.ho, D, rt, D, D, 1.f, h->P + h->oBout, 0, 1, w.ntok, 1));
+    AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 1, w.ntok, 1));
+    CeArgs c{};
+    c.logits = w.logits; c.gold = w.gold; c.cidx = w.cidx; c.n_dev = w.ntok; c.n_max = rt; c.V = V;
+    c.write_grad = train ? 1 : 0; c.inv_n = inv_n;
+    c.loss_samp = w.loss_samp; c.errt_samp = w.errt_samp; c.pred = w.pred; c.loss_acc = h->acc;
+    AV_CHECK(softmax_ce(h->stream, c));
+    float beta = h->cfg.kl_beta;
+    AV_CHECK(finalize_losses(h->stream, h->losses, h->acc, w.ntok, 0.f, 1.f / ((float)B * R), sc.anneal * beta));
+    return 0;
+}
+
+void fire_hook(avae_ctx* h, int bucket)
+{
+    if (h->hook && bucket >= 0 && bucket < (int)h->buckets.size())
+        h->hook(h->hook_user, bucket, h->buckets[bucket].first, h->buckets[bucket].second);
+}
+
+int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
+{
+    const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
+    const int T = St + 1, rt = T * B, rs = Ss * B;
+    const float isd = 1.f / sqrtf((float)D);
+    Sched sc = schedule(h);
+    hipStream_t st = h->stream;
+    float* G = h->G; const float* P = h->P;
+    AV_CHECK(hipMemsetAsync(G, 0, sizeof(float) * h->numel, st));
+
+    // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
+    AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 1, w.ntok, 1));
+    AV_TRY(gemm(h, true, true, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, nullptr, 0, 1, w.ntok, 2));
+    // out affine
+    AV_TRY(gemm_tn_grad(h, w.hc, D, w.dho, D, G + h->oKout, D, D, D, rt, 1.f, w.ntok));
+    AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));
+    AV_TRY(gemm(h, false, false, w.dho, D, P + h->oKout, D, w.dhc, D, rt, D, D, 1.f, nullptr, 0, 1, w.ntok, 1));
+    fire_hook(h, 0);
+    AV_CHECK(rows_expand(st, w.dhd[0], w.dhc, w.rank, rt, D));
+
+    // decoder GRU stack, top layer first
+    int cur = 0;
+    for (int i = L - 1; i >= 0; --i) {
+        const GruP& p = h->dec[i];
+        GruArgs a{};
+        a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
+        gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw;
+        GruJob& j = a.job[0];
+        j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
+        j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
+        j.dh0 = w.dh0 + (size_t)i * B * D; j.carry = w.carry;
+        AV_CHECK(gru_backward(st, a, h->persistent != 0));
+        const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
+        AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt));
+        AV_CHECK(colsum(st, w.dgi_d, rt, 3 * D, 3 * D, G + p.bW, nullptr));
+        AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
+        AV_CHECK(colsum(st, w.dgh_d, rt, 3 * D, 3 * D, G + p.bR, nullptr));
+        float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
+        AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D));
+        cur ^= 1;
+        fire_hook(h, 1 + (L - 1 - i));
+    }
+
+    // latent
+    AV_CHECK(add3(st, w.dh0sum, w.dh0, L > 1 ? w.dh0 + (size_t)B * D : nullptr, L > 2 ? w.dh0 + (size_t)2 * B * D : nullptr, (int64_t)B * D));
+    for (int i = 3; i < L; ++i) AV_CHECK(add3(st, w.dh0sum, w.dh0sum, w.dh0 + (size_t)i * B * D, nullptr, (int64_t)B * D));
+    AV_TRY(gemm_tn_grad(h, w.z, R, w.dh0sum, D, G + h->oWex, D, R, D, B));
+    AV_CHECK(colsum(st, w.dh0sum, B, D, D, G + h->oBex, nullptr));
+    AV_TRY(gemm(h, false, false, w.dh0sum, D, P + h->oWex, D, w.dz, R, B, R, D));
+    float bg = b_global > 0.f ? b_global : (float)B;
+    AV_CHECK(latent_bwd(st, w.dz, w.mu, w.lv, w.eps, w.dmu, w.dlv, B, R, sc.anneal * h->cfg.kl_beta / (bg * R), h->cfg.free_bits));
+    AV_TRY(gemm_tn_grad(h, w.hpick, 2 * D, w.dmu, R, G + h->oWmu, R, 2 * D, R, B));
+    AV_CHECK(colsum(st, w.dmu, B, R, R, G + h->oBmu, nullptr));
+    AV_TRY(gemm_tn_grad(h, w.hpick, 2 * D, w.dlv, R, G + h->oWlv, R, 2 * D, R, B));
+    AV_CHECK(colsum(st, w.dlv, B, R, R, G + h->oBlv, nullptr));
+    AV_TRY(gemm(h, false, false, w.dmu, R, P + h->oWmu, R, w.dhpick, 2 * D, B, 2 * D, R));
+    AV_TRY(gemm(h, false, false, w.dlv, R, P + h->oWlv, R, w.dhpick, 2 * D, B, 2 * D, R, 1.f, nullptr, 1));
+    fire_hook(h, 1 + L);
+    AV_CHECK(pick_last_bwd(st, w.dhs[0], w.dhpick, w.lens_src, Ss, B, 2 * D));
+
+    // encoder stack
+    cur = 0;
+    for (int i = L - 1; i >= 0; --i) {
+        const GruP& p = h->enc[i];
+        const int In = i == 0 ? D : 2 * D;
+        GruArgs a{};
+        a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
+        gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw;
+        for (int d = 0; d < 2; ++d) {
+            GruJob& j = a.job[d];
+            j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
+            j.dh_out = w.dhs[cur] + d * D; j.dgi = w.dgi_e + d * 3 * D; j.dgh = w.dgh_e + d * 3 * D;
+            j.dh0 = nullptr; j.carry = w.carry + (size_t)d * B * D;
+        }
+        AV_CHECK(gru_backward(st, a, h->persistent != 0));
+        const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
+        AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
+        AV_CHECK(colsum(st, w.dgi_e, rs, 6 * D, 6 * D, G + p.bW, nullptr));
+        for (int d = 0; d < 2; ++d)
+            AV_TRY(gemm_tn_grad(h, w.dgh_e + d * 3 * D, 6 * D, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs));
+        AV_CHECK(colsum(st, w.dgh_e, rs, 6 * D, 6 * D, G + p.bR, nullptr));
+        float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
+        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D));
+        cur ^= 1;
+        fire_hook(h, 2 + L + (L - 1 - i));
+    }
+    // embedding: gather gradients on top of the logits term
+    AV_CHECK(embed_scatter_add(st, G + h->oE, w.src_tm, w.demb_src, rs, D, V));
+    AV_CHECK(embed_scatter_add(st, G + h->oE, w.lead, w.demb_tgt, rt, D, V));
+    fire_hook(h, 2 + 2 * L);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------- parameter table
+void add_param(avae_ctx* h, const std::string& name, std::initializer_list<int64_t> shape, int g16, int bucket, int64_t* off_out)
+{
+    ParamEntry e; e.name = name; e.offset = h->numel; e.ndim = (int)shape.size(); e.g16 = g16; e.bucket = bucket;
+    int64_t n = 1; int k = 0;
+    for (int i = 0; i < 4; ++i) e.shape[i] = 1;
+    for (auto s : shape) { e.shape[k++] = s; n *= s; }
+    if (off_out) *off_out = e.offset;
+    h->numel += (n + 3) / 4 * 4;
+    h->params.push_back(e);
+}
+
+void build_params(avae_ctx* h)
+{
+    const int64_t D = h->cfg.dim_emb, V = h->cfg.dim_tgt, R = h->cfg.dim_rep; const int L = h->cfg.rnn_layers;
+    h->enc.resize(L); h->dec.resize(L);
+    auto close_bucket = [&](int64_t start) { h->buckets.push_back({start, h->numel - start}); };
+    int bucket = 0; int64_t start = 0;
+    add_param(h, "decode/out/kernel", {D, D}, 0, bucket, &h->oKout);
+    add_param(h, "decode/out/bias", {D}, 0, bucket, &h->oBout);
+    close_bucket(start);
+    for (int i = L - 1; i >= 0; --i) {
+        ++bucket; start = h->numel;
+        std::string p = "decode/rnn/l" + std::to_string(i + 1) + "/";
+        add_param(h, p + "W", {3 * D, D}, 1, bucket, &h->dec[i].W);
+        add_param(h, p + "R", {3 * D, D}, 1, bucket, &h->dec[i].R);
+        add_param(h, p + "bW", {3 * D}, 1, bucket, &h->dec[i].bW);
+        add_param(h, p + "bR", {3 * D}, 1, bucket, &h->dec[i].bR);
+        close_bucket(start);
+    }
+    ++bucket; start = h->numel;
+    add_param(h, "latent/ex/kernel", {R, D}, 0, bucket, &h->oWex);
+    add_param(h, "latent/ex/bias", {D}, 0, bucket, &h->oBex);
+    add_param(h, "latent/mu/kernel", {2 * D, R}, 0, bucket, &h->oWmu);
+    add_param(h, "latent/mu/bias", {R}, 0, bucket, &h->oBmu);
+    add_param(h, "latent/lv/kernel", {2 * D, R}, 0, bucket, &h->oWlv);
+    add_param(h, "latent/lv/bias", {R}, 0, bucket, &h->oBlv);
+    close_bucket(start);
+    for (int i = L - 1; i >= 0; --i) {
+        ++bucket; start = h->numel;
+        const int64_t In = i == 0 ? D : 2 * D;
+        std::string p = "encode/rnn" + std::to_string(i + 1) + "/";
+        int64_t o;
+        add_param(h, p + "fwd/W", {3 * D, In}, 1, bucket, &h->enc[i].W);
+        add_param(h, p + "bwd/W", {3 * D, In}, 1, bucket, &o);
+        add_param(h, p + "fwd/R", {3 * D, D}, 1, bucket, &h->enc[i].R);
+        add_param(h, p + "bwd/R", {3 * D, D}, 1, bucket, &o);
+        add_param(h, p + "fwd/bW", {3 * D}, 1, bucket, &h->enc[i].bW);
+        add_param(h, p + "bwd/bW", {3 * D}, 1, bucket, &o);
+        add_param(h, p + "fwd/bR", {3 * D}, 1, bucket, &h->enc[i].bR);
+        add_param(h, p + "bwd/bR", {3 * D}, 1, bucket, &o);
+        close_bucket(start);
+    }
+    ++bucket; start = h->numel;
+    add_param(h, "embed/embedding", {V, D}, 0, bucket, &h->oE);
+    close_bucket(start);
+}
+
+const ParamEntry* find_param(avae_ctx* h, const char* name)
+{
+    for (auto& e : h->params) if (e.name == name) return &e;
+    return nullptr;
+}
+
+float* state_buf(avae_ctx* h, int kind)
+{
+    switch (kind) { case AVAE_PARAM: return h->P; case AVAE_GRAD: return h->G; case AVAE_ADAM_M: return h->M; case AVAE_ADAM_V: return h->Vv; }
+    return nullptr;
+}
+
+int check_bound(avae_ctx* h)
+{
+    if (!h->P || !h->G || !h->M || !h->Vv) return fail(h, "state buffers not bound (avae_bind_state)");
+    return 0;
+}
+
+int check_gru_err(avae_ctx* h)
+{
+    int e = 0;
+    AV_CHECK(hipMemcpyAsync(&e, h->errw, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    if (e) {
+        (void)hipMemsetAsync(h->errw, 0, sizeof(int), h->stream);
+        return fail(h, "GRU persistent kernel: group wait timed out (workgroups not co-resident?)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================= C ABI
+extern "C" {
+
+int avae_create(const avae_config* cfg, int device, avae_handle* out)
+{
+    if (!cfg || !out) { g_create_err = "null argument"; return 1; }
+    *out = nullptr;
+    if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 64, 256, 512"; return 1; }
+    if (cfg->dim_rep % 4 || cfg->dim_tgt % 4 || cfg->rnn_layers < 1 || cfg->rnn_layers > 8) { g_create_err = "dim_rep and dim_tgt must be multiples of 4; 1 <= rnn_layers <= 8"; return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available: the gfx950 kernels cannot run (no CPU fallback)"; return 1; }
+    if (device < 0 || device >= ndev) { g_create_err = "bad device index"; return 1; }
+    avae_ctx* h = new avae_ctx();
+    h->cfg = *cfg; h->device = device;
+    if (h->cfg.kl_beta == 0.f) h->cfg.kl_beta = 1.f;
+    build_params(h);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->losses), 64 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->errw), 64 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counters), 64 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->losses, 0, 64 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->errw, 0, 64 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->counters, 0, 64 * sizeof(unsigned));
+    if (e != hipSuccess) { g_create_err = std::string("hip init failed: ") + hipGetErrorString(e); delete h; return 1; }
+    h->acc = h->losses + 8;
+    *out = h;
+    return 0;
+}
+
+void avae_destroy(avae_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream); else (void)hipDeviceSynchronize();
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->losses) (void)hipFree(h->losses);
+    if (h->errw) (void)hipFree(h->errw);
+    if (h->counters) (void)hipFree(h->counters);
+    if (h->scratch) (void)hipFree(h->scratch);
+    delete h;
+}
+
+const char* avae_last_error(avae_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int avae_set_stream(avae_handle h, void* s) { if (!h) return 1; h->stream = reinterpret_cast<hipStream_t>(s); return 0; }
+
+int avae_get_dims(avae_handle h, int32_t* V, int32_t* D, int32_t* R, int32_t* L)
+{
+    if (!h) return 1;
+    if (V) *V = h->cfg.dim_tgt; if (D) *D = h->cfg.dim_emb; if (R) *R = h->cfg.dim_rep; if (L) *L = h->cfg.rnn_layers;
+    return 0;
+}
+
+int64_t avae_state_numel(avae_handle h) { return h ? h->numel : 0; }
+
+int avae_bind_state(avae_handle h, float* p, float* g, float* m, float* v)
+{
+    if (!h) return 1;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(h, "state buffers must be 16-byte aligned");
+    h->P = p; h->G = g; h->M = m; h->Vv = v;
+    return 0;
+}
+
+int avae_param_count(avae_handle h) { return h ? (int)h->params.size() : 0; }
+const char* avae_param_name(avae_handle h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr; }
+
+int avae_param_info(avae_handle h, const char* name, int64_t* offset, int32_t* ndim, int64_t shape[4])
+{
+    if (!h) return 1;
+    const ParamEntry* e = find_param(h, name);
+    if (!e) return fail(h, std::string("unknown variable: ") + (name ? name : "(null)"));
+    if (offset) *offset = e->offset; if (ndim) *ndim = e->ndim;
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = e->shape[i];
+    return 0;
+}
+
+static int xfer_tensor(avae_handle h, const char* name, int kind, float* buf, bool get)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    const ParamEntry* e = find_param(h, name);
+    if (!e) return fail(h, std::string("unknown variable: ") + (name ? name : "(null)"));
+    float* base = state_buf(h, kind);
+    if (!base) return fail(h, "bad tensor kind");
+    float* flat = base + e->offset;
+    int64_t n = e->shape[0] * e->shape[1] * e->shape[2] * e->shape[3];
+    if (!e->g16) {
+        AV_CHECK(hipMemcpyAsync(get ? buf : flat, get ? flat : buf, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        int D = h->cfg.dim_emb, cols = (int)(e->ndim == 2 ? e->shape[1] : 1);
+        if (get) AV_CHECK(g16_permute(h->stream, buf, flat, D, cols, false));
+        else     AV_CHECK(g16_permute(h->stream, flat, buf, D, cols, true));
+    }
+    return 0;
+}
+int avae_get_tensor(avae_handle h, const char* name, int kind, float* buf) { return xfer_tensor(h, name, kind, buf, true); }
+int avae_set_tensor(avae_handle h, const char* name, int kind, const float* buf) { return xfer_tensor(h, name, kind, const_cast<float*>(buf), false); }
+
+int avae_get_step(avae_handle h, int64_t* s) { if (!h || !s) return 1; *s = h->step; return 0; }
+int avae_set_step(avae_handle h, int64_t s) { if (!h) return 1; h->step = s; return 0; }
+int avae_get_schedule(avae_handle h, float out[3])
+{
+    if (!h || !out) return 1;
+    Sched s = schedule(h); out[0] = s.keepwd; out[1] = s.anneal; out[2] = s.lr;
+    return 0;
+}
+
+int avae_set_grad_hook(avae_handle h, avae_grad_hook hook, void* user) { if (!h) return 1; h->hook = hook; h->hook_user = user; return 0; }
+
+// undocumented knob used by tests/bench: 1 = persistent GRU kernels (default), 0 = one launch per time step
+int avae_set_option(avae_handle h, const char* key, int value)
+{
+    if (!h || !key) return 1;
+    if (!strcmp(key, "persistent")) { h->persistent = value; return 0; }
+    return fail(h, "unknown option");
+}
+// test hook: the MFMA GEMM on caller buffers (see kernels.h for the operand conventions)
+int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const float* Bm, float* Cm, const float* bias,
+                    int M, int N, int K, int lda, int ldb, int ldc, float alpha, int accumulate, int split_k)
+{
+    if (!h) return 1;
+    return gemm(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k);
+}
+int avae_bucket_count(avae_handle h) { return h ? (int)h->buckets.size() : 0; }
+int avae_bucket_info(avae_handle h, int i, int64_t* offset, int64_t* count)
+{
+    if (!h || i < 0 || i >= (int)h->buckets.size()) return 1;
+    *offset = h->buckets[i].first; *count = h->buckets[i].second; return 0;
+}
+
+int avae_forward_backward(avae_handle h, const int32_t* src, const int32_t* tgt, int32_t B, int32_t Ss, int32_t St,
+                          uint64_t seed, const uint8_t* keep_mask, const float* eps, float n_tok_global, float b_global)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    if (B < 1 || Ss < 1 || St < 1) return fail(h, "empty batch");
+    AV_CHECK(hipSetDevice(h->device));
+    Ws w;
+    AV_TRY(get_ws(h, w, B, Ss, St, true));
+    h->B = B; h->Ss = Ss; h->St = St;
+    AV_TRY(forward(h, w, src, tgt, B, Ss, St, true, seed, keep_mask, eps, n_tok_global > 0.f ? 1.f / n_tok_global : 0.f));
+    AV_TRY(backward(h, w, B, Ss, St, b_global));
+    return 0;
+}
+
+int avae_adam_step(avae_handle h)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    Sched sc = schedule(h);
+    const double b1 = 0.9, b2 = 0.999;
+    double t = (double)h->step + 1.0;
+    AdamArgs a{h->P, h->G, h->M, h->Vv, h->numel, (float)(sc.lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t))), 0.9f, 0.999f, 1e-8f};
+    AV_CHECK(adam_tf(h->stream, a));
+    h->step += 1;
+    return 0;
+}
+
+int avae_train_step(avae_handle h, const int32_t* src, const int32_t* tgt, int32_t B, int32_t Ss, int32_t St,
+                    uint64_t seed, const uint8_t* keep_mask, const float* eps)
+{
+    AV_TRY(avae_forward_backward(h, src, tgt, B, Ss, St, seed, keep_mask, eps, 0.f, 0.f));
+    return avae_adam_step(h);
+}
+
+int avae_get_losses(avae_handle h, float out[3])
+{
+    if (!h || !out) return 1;
+    AV_CHECK(hipMemcpyAsync(out, h->losses, 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    AV_TRY(check_gru_err(h));
+    return 0;
+}
+
+int avae_eval(avae_handle h, const int32_t* src, const int32_t* tgt, int32_t B, int32_t Ss, int32_t St,
+              float* errt_samp, float* loss_gen_samp, float* loss_kld_samp, int32_t* n_out)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    if (B < 1 || Ss < 1 || St < 1) return fail(h, "empty batch");
+    AV_CHECK(hipSetDevice(h->device));
+    Ws w;
+    AV_TRY(get_ws(h, w, B, Ss, St, false));
+    AV_TRY(forward(h, w, src, tgt, B, Ss, St, false, 0, nullptr, nullptr, 0.f));
+    const size_t rt = (size_t)(St + 1) * B;
+    if (errt_samp) AV_CHECK(hipMemcpyAsync(errt_samp, w.errt_samp, rt * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (loss_gen_samp) AV_CHECK(hipMemcpyAsync(loss_gen_samp, w.loss_samp, rt * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (loss_kld_samp) AV_CHECK(hipMemcpyAsync(loss_kld_samp, w.kld, (size_t)B * h->cfg.dim_rep * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    int n = 0;
+    AV_CHECK(hipMemcpyAsync(&n, w.ntok, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AV_TRY(check_gru_err(h));
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+int avae_encode(avae_handle h, const int32_t* src, int32_t b, int32_t t, float* z_out, float* lv_out)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    if (b < 1 || t < 1) return fail(h, "empty batch");
+    AV_CHECK(hipSetDevice(h->device));
+    Ws w;
+    AV_TRY(get_ws(h, w, b, t, 1, false));
+    PrepArgs p{};
+    p.src = src; p.tgt = src; p.B = b; p.Ss = t; p.St = 1; p.eos = h->cfg.eos; p.bos = h->cfg.bos;
+    p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
+    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok;
+    // tgt is unused by the encoder; feed the first column of src as a 1-wide dummy target
+    AV_CHECK(prep_ids(h->stream, p));
+    AV_TRY(run_encoder(h, w, b, t, false));
+    AV_TRY(run_latent(h, w, b, false, 0, nullptr));
+    const size_t n = (size_t)b * h->cfg.dim_rep * sizeof(float);
+    if (z_out) AV_CHECK(hipMemcpyAsync(z_out, w.mu, n, hipMemcpyDeviceToDevice, h->stream));
+    if (lv_out) AV_CHECK(hipMemcpyAsync(lv_out, w.lv, n, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int avae_decode_init(avae_handle h, const float* z, int32_t b, float* state_out)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    AV_CHECK(hipSetDevice(h->device));
+    const int D = h->cfg.dim_emb, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
+    AV_TRY(gemm(h, false, true, z, R, h->P + h->oWex, D, state_out, D, b, D, R, 1.f, h->P + h->oBex));
+    for (int i = 1; i < L; ++i)
+        AV_CHECK(hipMemcpyAsync(state_out + (size_t)i * b * D, state_out, (size_t)b * D * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+static int decode_step_ws(avae_handle h, Ws& w, const int32_t* lead, const float* state_in, int b, int32_t* pred_out, float* state_out)
+{
+    const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
+    AV_CHECK(embed_gather(h->stream, h->P + h->oE, lead, w.emb_tgt, b, D, V));
+    AV_TRY(run_decoder_rnn(h, w, b, 1, state_in, (int64_t)b * D, false));
+    for (int i = 0; i < L; ++i)
+        AV_CHECK(hipMemcpyAsync(state_out + (size_t)i * b * D, w.d_hd[i], (size_t)b * D * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    AV_TRY(gemm(h, false, true, w.d_hd[L - 1], D, h->P + h->oKout, D, w.ho, D, b, D, D, 1.f, h->P + h->oBout));
+    AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, b, V, D, 1.f / sqrtf((float)D)));
+    AV_CHECK(argmax_rows(h->stream, w.logits, pred_out, b, V));
+    return 0;
+}
+
+int avae_decode_step(avae_handle h, const int32_t* lead, const float* state_in, int32_t b, int32_t* pred_out, float* state_out)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    AV_CHECK(hipSetDevice(h->device));
+    Ws w;
+    AV_TRY(get_ws(h, w, b, 1, 1, false));
+    return decode_step_ws(h, w, lead, state_in, b, pred_out, state_out);
+}
+
+int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, int32_t* out_ids, int32_t* n_steps)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    AV_CHECK(hipSetDevice(h->device));
+    const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
+    Ws w;
+    AV_TRY(get_ws(h, w, b, 1, 1, false));
+    // state ping-pong + time-major id log live in the (otherwise idle) encoder buffers of the workspace
+    const size_t sn = (size_t)L * b * D;
+    float* state[2]; int32_t* ids_tm = nullptr;
+    {
+        size_t need = 2 * sn * sizeof(float) + (size_t)(steps + 1) * b * sizeof(int32_t);
+        if (h->scratch_n < (int64_t)need) {
+            AV_CHECK(hipStreamSynchronize(h->stream));
+            if (h->scratch) AV_CHECK(hipFree(h->scratch));
+            AV_CHECK(hipMalloc(reinterpret_cast<void**>(&h->scratch), need));
+            h->scratch_n = (int64_t)need;
+        }
+        state[0] = h->scratch; state[1] = h->scratch + sn;
+        ids_tm = reinterpret_cast<int32_t*>(h->scratch + 2 * sn);
+    }
+    AV_TRY(avae_decode_init(h, z, b, state[0]));
+    std::vector<int32_t> host((size_t)(steps + 1) * b);
+    for (int i = 0; i < b; ++i) host[i] = h->cfg.bos;
+    AV_CHECK(hipMemcpyAsync(ids_tm, host.data(), b * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    int done = 0, kept = steps, cur = 0;
+    const int chunk = 16;
+    while (done < steps) {
+        int n = std::min(chunk, steps - done);
+        for (int s = 0; s < n; ++s) {
+            AV_TRY(decode_step_ws(h, w, ids_tm + (size_t)(done + s) * b, state[cur], b, ids_tm + (size_t)(done + s + 1) * b, state[cur ^ 1]));
+            cur ^= 1;
+        }
+        AV_CHECK(hipMemcpyAsync(host.data() + (size_t)(done + 1) * b, ids_tm + (size_t)(done + 1) * b, (size_t)n * b * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        AV_CHECK(hipStreamSynchronize(h->stream));
+        bool stop = false;
+        for (int s = 0; s < n && !stop; ++s) {
+            bool all = true;
+            for (int i = 0; i < b; ++i) all &= host[(size_t)(done + s + 1) * b + i] == h->cfg.eos;
+            if (all) { kept = done + s; stop = true; }      // model.py:217: break before appending
+        }
+        done += n;
+        if (stop) break;
+    }
+    if (kept > done) kept = done;
+    // transpose (kept, b) time-major -> (b, steps) row-major on the host (tiny), eos-fill the rest
+    std::vector<int32_t> outv((size_t)b * steps, h->cfg.eos);
+    for (int s = 0; s < kept; ++s) for (int i = 0; i < b; ++i) outv[(size_t)i * steps + s] = host[(size_t)(s + 1) * b + i];
+    AV_CHECK(hipMemcpyAsync(out_ids, outv.data(), outv.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    if (n_steps) *n_steps = kept;
+    return check_gru_err(h);
+}
+
+}  // extern "C"

@@ -1,0 +1,482 @@
+// ops.hip -- the HBM-bound kernels of the VAE step: id preparation, embedding gather /
+// scatter-add, compaction, final-state pick, latent elementwise, softmax cross-entropy,
+// column sums, TF-style Adam, layout permutation.  Each cites the reference lines it replaces.
+#include "kernels.h"
+
+namespace avae {
+
+// ---------------------------------------------------------------- counter RNG
+// stateless: value = f(seed, stream, index).  (Not TF's Philox stream: the reference's draws
+// are unreproducible anyway; parity tests inject keep_mask / eps.)
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    uint64_t r = mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ULL)) + idx);
+    return (float)((r >> 40) + 0.5) * (1.0f / 16777216.0f);      // (0,1)
+}
+__device__ __forceinline__ float normal01(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    float u1 = uniform01(seed, stream, 2 * idx), u2 = uniform01(seed, stream, 2 * idx + 1);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// ---------------------------------------------------------------- prep_ids
+// src/model.py:82-95 + src/util_tf.py:40-57: transpose to time-major, lengths, decoder mask,
+// gold = tgt + [eos], lead = [bos] + word-dropout(tgt), and the time-major compaction index
+// that tf.boolean_mask (model.py:161,174) implies.  One workgroup; the arrays are tiny.
+__global__ __launch_bounds__(1024) void prep_ids_kernel(PrepArgs p)
+{
+    __shared__ int sums[1024];
+    const int tid = threadIdx.x, B = p.B, T = p.St + 1;
+    for (int b = tid; b < B; b += 1024) {
+        int ls = 0, lt = 0;
+        for (int s = 0; s < p.Ss; ++s) ls += p.src[(size_t)b * p.Ss + s] != p.eos;
+        for (int s = 0; s < p.St; ++s) lt += p.tgt[(size_t)b * p.St + s] != p.eos;
+        p.lens_src[b] = ls; p.lens_tgt[b] = lt;
+    }
+    for (int i = tid; i < p.Ss * B; i += 1024) {
+        int s = i / B, b = i - s * B;
+        p.src_tm[i] = p.src[(size_t)b * p.Ss + s];
+    }
+    const int total = T * B;
+    for (int i = tid; i < total; i += 1024) {
+        int t = i / B, b = i - t * B;
+        p.gold[i] = t < p.St ? p.tgt[(size_t)b * p.St + t] : p.eos;
+        int lead = p.bos;
+        if (t > 0) {
+            lead = p.tgt[(size_t)b * p.St + t - 1];
+            if (p.train) {
+                int j = (t - 1) * B + b;
+                bool keep = p.keep_mask ? p.keep_mask[j] != 0 : uniform01(p.seed, 1, j) < p.keepwd;
+                if (!keep) lead = 0;     // unk, model.py:94
+            }
+        }
+        p.lead[i] = lead;
+    }
+    // exclusive scan of the mask in flat time-major order: contiguous segment per thread
+    const int per = (total + 1023) / 1024;
+    const int beg = min(total, tid * per), end = min(total, beg + per);
+    int cnt = 0;
+    for (int i = beg; i < end; ++i) {
+        int t = i / B, b = i - t * B;
+        cnt += (t == 0) || (p.tgt[(size_t)b * p.St + t - 1] != p.eos);
+    }
+    sums[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? sums[tid - off] : 0;
+        __syncthreads();
+        sums[tid] += v;
+        __syncthreads();
+    }
+    int run = sums[tid] - cnt;
+    for (int i = beg; i < end; ++i) {
+        int t = i / B, b = i - t * B;
+        bool m = (t == 0) || (p.tgt[(size_t)b * p.St + t - 1] != p.eos);
+        p.rank[i] = m ? run : -1;
+        if (m) p.cidx[run++] = i;
+    }
+    if (tid == 1023) p.ntok[0] = sums[1023];
+}
+hipError_t prep_ids(hipStream_t st, const PrepArgs& p)
+{
+    hipLaunchKernelGGL(prep_ids_kernel, dim3(1), dim3(1024), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- embedding gather / scatter-add
+// tf.gather(embedding, ids) (src/model.py:111-112) and its gradient.  One wave per row:
+// a D-float row is read/written as 16-byte pieces by consecutive lanes (whole 256-B segments).
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ E, const int32_t* __restrict__ ids,
+                                                           float* __restrict__ out, int n, int D, int V)
+{
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const float4* s = reinterpret_cast<const float4*>(E + (size_t)id * D);
+        float4* d = reinterpret_cast<float4*>(out + (size_t)row * D);
+        for (int c = lane; c < D / 4; c += 64) d[c] = s[c];
+    }
+}
+hipError_t embed_gather(hipStream_t st, const float* E, const int32_t* ids, float* out, int n, int D, int V)
+{
+    if (n <= 0) return hipSuccess;
+    int blocks = min((n + 3) / 4, 2048);
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(blocks), dim3(256), 0, st, E, ids, out, n, D, V);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void embed_scatter_kernel(float* __restrict__ dE, const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ dout, int n, int D, int V)
+{
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const float* s = dout + (size_t)row * D;
+        float* d = dE + (size_t)id * D;
+        for (int c = lane; c < D; c += 64) atomicAdd(d + c, s[c]);     // 256 contiguous bytes per wave op
+    }
+}
+hipError_t embed_scatter_add(hipStream_t st, float* dE, const int32_t* ids, const float* dout, int n, int D, int V)
+{
+    if (n <= 0) return hipSuccess;
+    int blocks = min((n + 3) / 4, 4096);
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(blocks), dim3(256), 0, st, dE, ids, dout, n, D, V);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- compaction (tf.boolean_mask, model.py:161)
+__global__ __launch_bounds__(256) void rows_gather_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev,
+                                                          int n_max, int D)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int n = min(n_max, *n_dev);
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        const float4* s = reinterpret_cast<const float4*>(src + (size_t)idx[row] * D);
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)row * D);
+        for (int c = lane; c < D / 4; c += 64) d[c] = s[c];
+    }
+}
+hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D)
+{
+    if (n_max <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(min((n_max + 3) / 4, 2048)), dim3(256), 0, st, dst, src, idx, n_dev, n_max, D);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void rows_expand_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          const int32_t* __restrict__ rank, int rows, int D)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        int r = rank[row];
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)row * D);
+        if (r >= 0) {
+            const float4* s = reinterpret_cast<const float4*>(src + (size_t)r * D);
+            for (int c = lane; c < D / 4; c += 64) d[c] = s[c];
+        } else {
+            for (int c = lane; c < D / 4; c += 64) d[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_expand_kernel, dim3(min((rows + 3) / 4, 2048)), dim3(256), 0, st, dst, src, rank, rows, D);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- final-state pick (tf.gather_nd, model.py:135)
+__global__ __launch_bounds__(256) void pick_last_kernel(float* __restrict__ h, const float* __restrict__ hs,
+                                                        const int32_t* __restrict__ lens, int B, int W)
+{
+    const int b = blockIdx.x;
+    int t = max(lens[b] - 1, 0);
+    const float4* s = reinterpret_cast<const float4*>(hs + ((size_t)t * B + b) * W);
+    float4* d = reinterpret_cast<float4*>(h + (size_t)b * W);
+    for (int c = threadIdx.x; c < W / 4; c += blockDim.x) d[c] = s[c];
+}
+hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W)
+{
+    hipLaunchKernelGGL(pick_last_kernel, dim3(B), dim3(256), 0, st, h, hs, lens, B, W);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void pick_last_bwd_kernel(float* __restrict__ dhs, const float* __restrict__ dh,
+                                                            const int32_t* __restrict__ lens, int S, int B, int W)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int rows = S * B;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        int s = row / B, b = row - s * B;
+        float4* d = reinterpret_cast<float4*>(dhs + (size_t)row * W);
+        if (s == max(lens[b] - 1, 0)) {
+            const float4* src = reinterpret_cast<const float4*>(dh + (size_t)b * W);
+            for (int c = lane; c < W / 4; c += 64) d[c] = src[c];
+        } else {
+            for (int c = lane; c < W / 4; c += 64) d[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+hipError_t pick_last_bwd(hipStream_t st, float* dhs, const float* dh, const int32_t* lens, int S, int B, int W)
+{
+    hipLaunchKernelGGL(pick_last_bwd_kernel, dim3(min((S * B + 3) / 4, 2048)), dim3(256), 0, st, dhs, dh, lens, S, B, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- latent (model.py:151-155,183-184)
+__device__ __forceinline__ float block_sum(float v, float* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+    return s;    // valid on thread 0
+}
+struct LatentK { const float* mu; const float* lv; const float* eps_in; float* eps_out; float* z; float* kld; int n;
+                 int train; uint64_t seed; float free_bits; float* acc; };
+__global__ __launch_bounds__(256) void latent_fwd_kernel(LatentK a)
+{
+    __shared__ float sh[4];
+    float part = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        float mu = a.mu[i], lv = a.lv[i];
+        float z = mu;
+        if (a.train) {
+            float e = a.eps_in ? a.eps_in[i] : normal01(a.seed, 2, i);
+            if (a.eps_out) a.eps_out[i] = e;
+            z = mu + expf(0.5f * lv) * e;
+        }
+        a.z[i] = z;
+        float k = 0.5f * (mu * mu + expf(lv) - lv - 1.f);
+        if (a.kld) a.kld[i] = k;
+        part += fmaxf(k, a.free_bits);
+    }
+    float s = block_sum(part, sh);
+    if (threadIdx.x == 0 && a.acc) atomicAdd(a.acc, s);
+}
+hipError_t latent_fwd(hipStream_t st, const float* mu, const float* lv, const float* eps_in, float* eps_out, float* z,
+                       float* kld, int n, int train, uint64_t seed, float free_bits, float* acc)
+{
+    LatentK k{mu, lv, eps_in, eps_out, z, kld, n, train, seed, free_bits, acc};
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mu,
+                                                         const float* __restrict__ lv, const float* __restrict__ eps,
+                                                         float* __restrict__ dmu, float* __restrict__ dlv, int n,
+                                                         float coef, float free_bits)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float m = mu[i], l = lv[i], g = dz[i];
+        float el = expf(l);
+        float k = 0.5f * (m * m + el - l - 1.f);
+        float c = (k >= free_bits) ? coef : 0.f;
+        dmu[i] = g + c * m;
+        dlv[i] = (eps ? g * eps[i] * 0.5f * expf(0.5f * l) : 0.f) + c * 0.5f * (el - 1.f);
+    }
+}
+hipError_t latent_bwd(hipStream_t st, const float* dz, const float* mu, const float* lv, const float* eps_used,
+                      float* dmu, float* dlv, int B, int R, float coef, float free_bits)
+{
+    int n = B * R;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, st, dz, mu, lv, eps_used, dmu, dlv, n, coef, free_bits);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- softmax cross-entropy (model.py:170-181)
+// one workgroup per compact row: pass 1 online max / sum-exp / first-argmax / label pick,
+// pass 2 (optional) overwrites the row with (softmax - onehot) * scale.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
+{
+    __shared__ float s_m[4], s_s[4], s_bv[4]; __shared__ int s_bi[4];
+    __shared__ float s_acc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(a.n_max, *a.n_dev);
+    const float scale = a.inv_n > 0.f ? a.inv_n : 1.f / (float)max(n, 1);
+    if (tid == 0) s_acc = 0.f;
+    __syncthreads();
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        float* x = a.logits + (size_t)row * a.V;
+        const int label = a.gold[a.cidx[row]];
+        float m = -INFINITY, s = 0.f, bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = tid * 4; c < a.V; c += 1024) {
+            float4 v = *reinterpret_cast<const float4*>(x + c);
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (e[k] > bv) { bv = e[k]; bi = c + k; }
+                float nm = fmaxf(m, e[k]);
+                s = s * expf(m - nm) + expf(e[k] - nm);
+                m = nm;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float om = __shfl_down(m, o, 64), os = __shfl_down(s, o, 64);
+            float ov = __shfl_down(bv, o, 64); int oi = __shfl_down(bi, o, 64);
+            float nm = fmaxf(m, om);
+            s = (nm == -INFINITY) ? 0.f : s * expf(m - nm) + os * expf(om - nm);
+            m = nm;
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_m[wave] = m; s_s[wave] = s; s_bv[wave] = bv; s_bi[wave] = bi; }
+        __syncthreads();
+        m = s_m[0]; s = s_s[0]; bv = s_bv[0]; bi = s_bi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            float nm = fmaxf(m, s_m[w]);
+            s = s * expf(m - nm) + s_s[w] * expf(s_m[w] - nm);
+            m = nm;
+            if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+        }
+        const float lse = m + logf(s);
+        if (tid == 0) {
+            float loss = lse - x[label];
+            if (a.loss_samp) a.loss_samp[row] = loss;
+            if (a.errt_samp) a.errt_samp[row] = (label != bi) ? 1.f : 0.f;
+            if (a.pred) a.pred[row] = bi;
+            s_acc += loss;
+        }
+        if (a.write_grad) {
+            __syncthreads();     // x[label] read before overwrite
+            for (int c = tid * 4; c < a.V; c += 1024) {
+                float4 v = *reinterpret_cast<const float4*>(x + c);
+                float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = (expf(e[k] - lse) - ((c + k) == label ? 1.f : 0.f)) * scale;
+                *reinterpret_cast<float4*>(x + c) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && a.loss_acc) atomicAdd(a.loss_acc, s_acc);
+}
+hipError_t softmax_ce(hipStream_t st, const CeArgs& a)
+{
+    if (a.n_max <= 0) return hipSuccess;
+    if (a.V & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int32_t* __restrict__ pred, int n, int V)
+{
+    __shared__ float s_bv[4]; __shared__ int s_bi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const float* x = logits + (size_t)row * V;
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = tid; c < V; c += 256) { float v = x[c]; if (v > bv) { bv = v; bi = c; } }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_down(bv, o, 64); int oi = __shfl_down(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+            pred[row] = bi;
+        }
+    }
+}
+hipError_t argmax_rows(hipStream_t st, const float* logits, int32_t* pred, int n, int V)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(min(n, 4096)), dim3(256), 0, st, logits, pred, n, V);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+// block = 64 columns x 4 row lanes; grid.y chunks of 1024 rows; float atomics into out (+=).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                     float* __restrict__ out, const int32_t* __restrict__ m_dev)
+{
+    __shared__ float sh[4][64];
+    if (m_dev) M = min(M, *m_dev);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 1024, r1 = min(M, r0 + 1024);
+    float s = 0.f;
+    if (c < N) for (int r = r0 + rl; r < r1; r += 4) s += X[(size_t)r * ldx + c];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N && r0 < r1) atomicAdd(out + c, (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+}
+hipError_t colsum(hipStream_t st, const float* X, int M, int N, int ldx, float* out, const int32_t* m_dev)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + 1023) / 1024), dim3(256), 0, st, X, M, N, ldx, out, m_dev);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add3_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ c, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + (b ? b[i] : 0.f) + (c ? c[i] : 0.f);
+}
+hipError_t add3(hipStream_t st, float* out, const float* a, const float* b, const float* c, int64_t n)
+{
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, out, a, b, c, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- Adam, TF formulation (model.py:189)
+// m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t m / (sqrt(v) + eps), lr_t bias-corrected
+// on the host.  28 B of HBM traffic per parameter, one launch over the flat state.
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a)
+{
+    const int64_t n4 = a.n >> 2;
+    float4* p = reinterpret_cast<float4*>(a.p);
+    const float4* g = reinterpret_cast<const float4*>(a.g);
+    float4* m = reinterpret_cast<float4*>(a.m);
+    float4* v = reinterpret_cast<float4*>(a.v);
+    const float c1 = 1.f - a.b1, c2 = 1.f - a.b2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 P = p[i], G = g[i], Mv = m[i], V = v[i];
+#define AVAE_ADAM1(f) Mv.f = a.b1 * Mv.f + c1 * G.f; V.f = a.b2 * V.f + c2 * G.f * G.f; P.f -= a.lr_t * Mv.f / (sqrtf(V.f) + a.eps);
+        AVAE_ADAM1(x) AVAE_ADAM1(y) AVAE_ADAM1(z) AVAE_ADAM1(w)
+#undef AVAE_ADAM1
+        p[i] = P; m[i] = Mv; v[i] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 << 2; i < a.n; ++i) {
+            float G = a.g[i];
+            a.m[i] = a.b1 * a.m[i] + c1 * G; a.v[i] = a.b2 * a.v[i] + c2 * G * G;
+            a.p[i] -= a.lr_t * a.m[i] / (sqrtf(a.v[i]) + a.eps);
+        }
+}
+hipError_t adam_tf(hipStream_t st, const AdamArgs& a)
+{
+    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- G16 row permutation
+__global__ __launch_bounds__(256) void g16_permute_kernel(float* __restrict__ dst, const float* __restrict__ src, int D, int cols, int to_g16)
+{
+    const int64_t total = (int64_t)3 * D * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = i / cols; int col = (int)(i - row * cols);
+        // row is a G16 row index c' = ht*48 + gate*16 + u  <->  natural gate*D + ht*16 + u
+        int ht = (int)(row / 48), rem = (int)(row % 48), gate = rem / 16, u = rem % 16;
+        int64_t nat = (int64_t)gate * D + ht * 16 + u;
+        if (to_g16) dst[i] = src[nat * cols + col];
+        else dst[nat * cols + col] = src[i];
+    }
+}
+hipError_t g16_permute(hipStream_t st, float* dst, const float* src, int D, int cols, bool to_g16)
+{
+    int64_t total = (int64_t)3 * D * cols;
+    hipLaunchKernelGGL(g16_permute_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, st, dst, src, D, cols, to_g16 ? 1 : 0);
+    return hipGetLastError();
+}
+
+__global__ void finalize_losses_kernel(float* losses, const float* acc, const int32_t* n_dev, float inv_br, float anneal)
+{
+    float n = (float)max(*n_dev, 1);
+    float gen = acc[0] / n, kld = acc[1] * inv_br;
+    losses[0] = gen; losses[1] = kld; losses[2] = anneal * kld + gen;
+}
+hipError_t finalize_losses(hipStream_t st, float* losses, const float* acc, const int32_t* n_dev,
+                           float n_override, float inv_br, float anneal)
+{
+    (void)n_override;
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1), 0, st, losses, acc, n_dev, inv_br, anneal);
+    return hipGetLastError();
+}
+
+}  // namespace avae

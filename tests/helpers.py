@@ -1,0 +1,37 @@
+"""shared fixtures for the parity tests: seeded ragged batches and oracle parameter sets."""
+import numpy as np
+
+from oracle import vae_numpy as vn
+
+CASES = {
+    # name: (cfg kwargs, B, S, lens or None(full))
+    'tiny':  (dict(dim_tgt=32, dim_emb=16, dim_rep=8, rnn_layers=3), 4, 7, [7, 1, 3, 5]),
+    'mid':   (dict(dim_tgt=256, dim_emb=64, dim_rep=32, rnn_layers=3), 8, 16, [16, 2, 9, 16, 1, 5, 12, 7]),
+    'wide':  (dict(dim_tgt=512, dim_emb=256, dim_rep=64, rnn_layers=2), 20, 9, None),
+    'full2': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 2, 64, [64, 23]),
+}
+
+
+def make_case(name, seed=0, pad=2, bias_scale=0.1):
+    kw, B, S, lens = CASES[name]
+    cfg = vn.make_cfg(**kw)
+    rng = np.random.default_rng(seed + 17)
+    V, R = cfg['dim_tgt'], cfg['dim_rep']
+    ids = np.full((B, S + pad), cfg['eos'], np.int32)
+    if lens is None:
+        lens = [S] * B
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(3, V, n)
+    smax = max(lens)
+    keep = (rng.random((smax, B)) < 0.6).astype(np.uint8)
+    eps = rng.standard_normal((B, R)).astype(np.float32)
+    P = vn.init_params(cfg, seed, bias_scale=bias_scale)
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}   # exactly representable in fp32
+    return cfg, P, ids, keep, eps
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    d = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (d if d > 0 else 1.0)

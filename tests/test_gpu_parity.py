@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (fp32 path vs float64 oracle; stated per quantity as SURVEY 8c asks):
+    z, mu, lv               <= 2e-5 abs
+    loss_gen, loss_kld      <= 2e-5 rel
+    per-sample CE           <= 1e-4 abs
+    gradients               <= 2e-4 relative L2 per variable
+    one Adam update         <= 1e-5 abs on the parameters (update magnitude is ~lr = 1e-3)
+    pred / errt             exact (integer) -- ties are vanishingly unlikely with random weights
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import CASES, make_case, rel_l2
+from oracle import vae_numpy as vn
+from oracle import vae_torch as vt
+
+pytestmark = pytest.mark.gpu
+
+
+def _vae(cfg, P, **kw):
+    from argsim_amd.model import VAE
+    keys = ('dim_tgt', 'dim_emb', 'dim_rep', 'rnn_layers', 'accelerate', 'learn_rate', 'bos', 'eos')
+    m = VAE('train', init=False, **{k: cfg[k] for k in keys}, **kw)
+    m.set_params(P)
+    return m
+
+
+@pytest.mark.parametrize("a_mc,b_nc", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 52), (4, 8, 16), (333, 260, 132), (1000, 512, 96)])
+def test_gemm(a_mc, b_nc, M, N, K):
+    import torch
+    from argsim_amd import lib
+    l = lib.load()
+    if a_mc:
+        M = (M + 3) // 4 * 4
+    if b_nc:
+        N = (N + 3) // 4 * 4
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = 0.5 * (A.astype(np.float64) @ B.astype(np.float64)) + bias
+    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0)
+    h = C.c_void_p()
+    assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
+    dev = torch.device('cuda', 0)
+    At = torch.tensor(A.T.copy() if a_mc else A, device=dev)
+    Bt = torch.tensor(B if b_nc else B.T.copy(), device=dev)
+    bt = torch.tensor(bias, device=dev)
+    lda = M if a_mc else K
+    ldb = N if b_nc else K
+    for acc, split in ((0, 1), (1, 1), (0, 3)):
+        Ct = torch.tensor(C0, device=dev) if acc else torch.zeros((M, N), device=dev)
+        rc = l.avae_debug_gemm(h, a_mc, b_nc, At.data_ptr(), Bt.data_ptr(), Ct.data_ptr(), bt.data_ptr(),
+                               M, N, K, lda, ldb, N, 0.5, acc, split)
+        assert rc == 0, l.avae_last_error(h)
+        torch.cuda.synchronize()
+        want = ref + (C0 if acc else 0.0)
+        got = Ct.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (acc, split)
+    l.avae_destroy(h)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encode_z(name):
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P)
+    z, lv = m.encode(ids, return_lv=True)
+    o = vn.forward(P, cfg, ids, ids, 'valid')
+    assert np.abs(z - o['mu']).max() <= 2e-5
+    assert np.abs(lv - o['lv']).max() <= 2e-5
+    # the stepwise (one launch per time step) and persistent GRU kernels must agree bit for bit
+    m.set_option('persistent', 0)
+    z2 = m.encode(ids)
+    assert np.array_equal(z, z2)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_eval_outputs(name):
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P)
+    errt, lgen, lkld = m.eval(ids, ids)
+    o = vn.forward(P, cfg, ids, ids, 'valid')
+    assert errt.shape == o['errt_samp'].shape
+    assert np.abs(lgen - o['loss_gen_samp']).max() <= 1e-4
+    assert np.abs(lkld - o['loss_kld_samp']).max() <= 2e-5
+    assert np.array_equal(errt, o['errt_samp'])
+    lg, lk, lo = m.losses()
+    assert abs(lg - o['loss_gen']) <= 2e-5 * abs(o['loss_gen'])
+    assert abs(lk - o['loss_kld']) <= 2e-5 * abs(o['loss_kld']) + 1e-7
+
+
+@pytest.mark.parametrize("persistent", [1, 0])
+@pytest.mark.parametrize("name", list(CASES))
+def test_gradients(name, persistent):
+    cfg, P, ids, keep, eps = make_case(name)
+    step = 20000                                   # anneal = tanh(2) so the KL backward is live
+    m = _vae(cfg, P)
+    m.set_option('persistent', persistent)
+    m.step = step
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    lg, lk, lo = m.losses()
+    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, step, keep, eps)
+    assert abs(lg - outs['loss_gen']) <= 2e-5 * abs(outs['loss_gen'])
+    assert abs(lk - outs['loss_kld']) <= 2e-5 * abs(outs['loss_kld'])
+    assert abs(lo - outs['loss']) <= 2e-5 * abs(outs['loss'])
+    got = m.get_grads()
+    bad = {k: rel_l2(got[k], grads[k]) for k in grads if rel_l2(got[k], grads[k]) > 2e-4}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ['tiny', 'mid'])
+def test_train_steps_match_oracle(name):
+    """three full steps (fwd + bwd + TF Adam + step increment) track the float64 oracle"""
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P)
+    step0 = 12345
+    m.step = step0
+    Pn = {k: v.copy() for k, v in P.items()}
+    mo = {k: np.zeros_like(v) for k, v in P.items()}
+    vo = {k: np.zeros_like(v) for k, v in P.items()}
+    for i in range(3):
+        m.train_step(ids, ids, keep_mask=keep, eps=eps)
+        outs, grads = vt.loss_and_grads(Pn, cfg, ids, ids, step0 + i, keep, eps)
+        lr = vn.schedule(step0 + i, cfg['accelerate'], cfg['learn_rate'])[2]
+        Pn, mo, vo = vn.adam_tf(Pn, grads, mo, vo, i, lr)
+        # NB: TF's beta powers count optimizer applications, the library counts global_step;
+        # the library therefore uses t = step + 1.  Compare with that convention:
+    assert m.step == step0 + 3
+    # the oracle above used n_updates = i; the library uses global_step -- re-run the oracle the same way
+    Pn = {k: v.copy() for k, v in P.items()}
+    mo = {k: np.zeros_like(v) for k, v in P.items()}
+    vo = {k: np.zeros_like(v) for k, v in P.items()}
+    for i in range(3):
+        outs, grads = vt.loss_and_grads(Pn, cfg, ids, ids, step0 + i, keep, eps)
+        lr = vn.schedule(step0 + i, cfg['accelerate'], cfg['learn_rate'])[2]
+        Pn, mo, vo = vn.adam_tf(Pn, grads, mo, vo, step0 + i, lr)
+    got = m.get_params()
+    for k in Pn:
+        assert np.abs(got[k] - Pn[k]).max() <= 1e-5, k
+
+
+def test_adam_first_update_from_step0():
+    cfg, P, ids, keep, eps = make_case('tiny')
+    m = _vae(cfg, P)
+    m.train_step(ids, ids, keep_mask=keep, eps=eps)
+    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, 0, keep, eps)
+    z = {k: np.zeros_like(v) for k, v in P.items()}
+    Pn, _, _ = vn.adam_tf(P, grads, z, z, 0, vn.schedule(0)[2])
+    got = m.get_params()
+    for k in Pn:
+        assert np.abs(got[k] - Pn[k]).max() <= 1e-5, k
+    assert m.step == 1
+
+
+@pytest.mark.parametrize("name", ['tiny', 'mid'])
+def test_decode_greedy(name):
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P)
+    o = vn.forward(P, cfg, ids, ids, 'valid')
+    want = vn.decode_greedy(P, cfg, o['mu'], steps=12)
+    got = m.decode(o['mu'].astype(np.float32), steps=12)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # single step entry: state_in from z, one step from bos
+    s = m.decode_init(o['mu'].astype(np.float32))
+    assert np.abs(s.cpu().numpy() - o['state_in']).max() <= 2e-5
+    pred, s2 = m.decode_step(np.full((1, len(ids)), cfg['bos'], np.int32), s)
+    assert np.array_equal(pred.cpu().numpy()[0], want[:, 0]) or want.shape[1] == 0
+
+
+def test_untrimmed_input_same_result():
+    """util_tf.trim drops all-eos tail columns; feeding them anyway must not change z or the losses"""
+    import torch
+    cfg, P, ids, keep, eps = make_case('mid', pad=5)
+    m = _vae(cfg, P)
+    z1 = m.encode(ids)
+    z2 = m.encode(torch.as_tensor(ids).cuda())          # device tensors are not trimmed on the host
+    assert np.array_equal(z1, z2)
+    e1 = m.eval(ids, ids)
+    e2 = m.eval(torch.as_tensor(ids).cuda(), torch.as_tensor(ids).cuda())
+    for a, b in zip(e1, e2):
+        assert np.array_equal(a, b)
+
+
+def test_random_draws_are_seeded_and_sane():
+    """without injected mask/eps the library draws its own: same seed -> same loss, different seed -> different"""
+    cfg, P, ids, keep, eps = make_case('mid')
+    m = _vae(cfg, P)
+    m.forward_backward(ids, ids, seed=11)
+    a = m.losses()
+    m.forward_backward(ids, ids, seed=11)
+    b = m.losses()
+    m.forward_backward(ids, ids, seed=12)
+    c = m.losses()
+    assert a[0] == b[0] and a[1] == b[1]
+    assert a[0] != c[0]
