@@ -60,6 +60,10 @@ struct avae_ctx {
     char* ws = nullptr; size_t ws_cap = 0;
     // last forward geometry
     int B = 0, Ss = 0, St = 0;
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
+    int timing = 0;
+    struct Stamp { hipEvent_t a, b; int cls; double flops; };
+    std::vector<Stamp> stamps; size_t stamps_used = 0;
 };
 
 namespace {
@@ -71,6 +75,23 @@ namespace {
 #define AV_TRY(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
 
 int fail(avae_ctx* h, const std::string& m) { h->err = m; return 1; }
+
+// kernel classes for the timing hook: 0 = MFMA GEMM, 1 = GRU forward, 2 = GRU backward
+struct Timed {
+    avae_ctx* h; avae_ctx::Stamp* s = nullptr;
+    Timed(avae_ctx* h_, int cls, double flops) : h(h_) {
+        if (!h->timing) return;
+        if (h->stamps_used == h->stamps.size()) {
+            avae_ctx::Stamp n{};
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            h->stamps.push_back(n);
+        }
+        s = &h->stamps[h->stamps_used++];
+        s->cls = cls; s->flops = flops;
+        (void)hipEventRecord(s->a, h->stream);
+    }
+    ~Timed() { if (s) (void)hipEventRecord(s->b, h->stream); }
+};
 
 // -------------------------------------------------------------------------------- workspace
 struct Ws {
@@ -167,6 +188,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
          const int* dyn = nullptr, int dyn_kind = 0)
 {
     GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind};
+    Timed t(h, 0, 2.0 * M * N * K);
     AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
     return 0;
 }
@@ -236,7 +258,8 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             j.hp = save ? w.e_hp[d][i] : nullptr;
             j.reverse = d;
         }
-        AV_CHECK(gru_forward(h->stream, a, h->persistent != 0));
+        { Timed t(h, 1, 2.0 * 2 * Ss * (double)B * D * 3 * D);
+          AV_CHECK(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.e_hs[i]; In = 2 * D;
     }
     AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D));
@@ -272,7 +295,8 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         j.sv = save ? w.d_sv[i] : nullptr;
         j.hp = save ? w.d_hp[i] : nullptr;
         j.reverse = 0;
-        AV_CHECK(gru_forward(h->stream, a, h->persistent != 0));
+        { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
+          AV_CHECK(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.d_hd[i];
     }
     return 0;
@@ -347,7 +371,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
         j.dh0 = w.dh0 + (size_t)i * B * D; j.carry = w.carry;
-        AV_CHECK(gru_backward(st, a, h->persistent != 0));
+        { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
+          AV_CHECK(gru_backward(st, a, h->persistent != 0)); }
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt));
         AV_CHECK(colsum(st, w.dgi_d, rt, 3 * D, 3 * D, G + p.bW, nullptr));
@@ -391,7 +416,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             j.dh_out = w.dhs[cur] + d * D; j.dgi = w.dgi_e + d * 3 * D; j.dgh = w.dgh_e + d * 3 * D;
             j.dh0 = nullptr; j.carry = w.carry + (size_t)d * B * D;
         }
-        AV_CHECK(gru_backward(st, a, h->persistent != 0));
+        { Timed t(h, 2, 2.0 * 2 * (Ss - 1) * (double)B * D * 3 * D);
+          AV_CHECK(gru_backward(st, a, h->persistent != 0)); }
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         AV_CHECK(colsum(st, w.dgi_e, rs, 6 * D, 6 * D, G + p.bW, nullptr));
@@ -614,7 +640,24 @@ int avae_set_option(avae_handle h, const char* key, int value)
 {
     if (!h || !key) return 1;
     if (!strcmp(key, "persistent")) { h->persistent = value; return 0; }
+    if (!strcmp(key, "timing")) { h->timing = value; h->stamps_used = 0; return 0; }
     return fail(h, "unknown option");
+}
+// synchronises, sums the HIP-event durations recorded since timing was switched on / last collected:
+// out[3*c + 0..2] = total ms, launches, algorithmic FLOPs of kernel class c (0 GEMM, 1 GRU fwd, 2 GRU bwd)
+int avae_timing_collect(avae_handle h, double* out)
+{
+    if (!h || !out) return 1;
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 9; ++i) out[i] = 0.0;
+    for (size_t i = 0; i < h->stamps_used; ++i) {
+        float ms = 0.f;
+        AV_CHECK(hipEventElapsedTime(&ms, h->stamps[i].a, h->stamps[i].b));
+        int c = h->stamps[i].cls;
+        out[3 * c] += ms; out[3 * c + 1] += 1.0; out[3 * c + 2] += h->stamps[i].flops;
+    }
+    h->stamps_used = 0;
+    return 0;
 }
 // test hook: the MFMA GEMM on caller buffers (see kernels.h for the operand conventions)
 int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const float* Bm, float* Cm, const float* bias,

@@ -169,6 +169,13 @@ class VAE:
     def set_option(self, key, value):
         self._ck(self._l.avae_set_option(self._h, key.encode(), int(value)))
 
+    def timing_collect(self):
+        """{class: (ms, launches, flops)} from the HIP events recorded while option 'timing' was on"""
+        out = (C.c_double * 9)()
+        self._stream()
+        self._ck(self._l.avae_timing_collect(self._h, out))
+        return {k: (out[3 * i], int(out[3 * i + 1]), out[3 * i + 2]) for i, k in enumerate(('gemm', 'gru_fwd', 'gru_bwd'))}
+
     def buckets(self):
         out = []
         for i in range(self._l.avae_bucket_count(self._h)):

@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- sentences/sec per ELBO step (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full ELBO training step (forward + hand-written backward + TF-style Adam, plus the
+RCCL gradient all-reduce when N > 1) over one synthetic FULL batch already resident in HBM.
+Workload at every N: BASELINE.json configs[1] per GPU -- fp32, batch 256 x seq 64, vocab 8192,
+dim_emb 512, latent 128, 3 layers (weak scaling: the per-GPU batch is fixed, global batch 256 N).
+
+Extra objects on the JSON line (N = 1, rank 0):
+  roofline      the kernel class with the largest share of the step, its algorithmic FLOPs per launch
+                divided by its mean launch duration from HIP events recorded on the launch stream
+                during the timed steps, against the fp32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline  the torch-CPU restatement (oracle/vae_torch.py, "port": the reference's TF graph has
+                a GPU-only CudnnGRU and TensorFlow is absent) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+B, S = 256, 64
+PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md chip table
+
+
+def cpu_baseline(sample_b=32, steps=2):
+    import numpy as np
+    import torch
+    from argsim_amd import synth
+    from oracle import vae_numpy as vn
+    from oracle import vae_torch as vt
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cfg = vn.make_cfg(**CFG)
+    P = vn.init_params(cfg, 0)
+    tr = vt.CpuTrainer(P, cfg)
+    tr.step = 20000
+    ids = synth.batch(sample_b, S, CFG['dim_tgt'], seed=0)
+    rng = np.random.default_rng(0)
+    keep = (rng.random((S, sample_b)) < 0.88).astype(np.int32)
+    eps = rng.standard_normal((sample_b, CFG['dim_rep'])).astype(np.float32)
+    tr.train_step(ids, ids, keep, eps)            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(ids, ids, keep, eps)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_b * steps / dt, unit="sentences/sec", cores=cores, kind="port",
+                sample="%d timed ELBO steps (fwd+bwd+Adam, fp32 torch-CPU restatement) on %d of the %d rows, seq %d"
+                       % (steps, sample_b, B, S))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--stepwise', action='store_true', help="one GRU launch per time step instead of the persistent kernels")
+    A = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == A.gpus, "launch with torch.distributed.run --nproc-per-node %d" % A.gpus
+    torch.cuda.set_device(local)
+    dp = None
+    model = VAE('train', device=local, seed=0, **CFG)
+    if world > 1:
+        from argsim_amd.dist import DataParallel
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        dp = DataParallel(model)
+        dp.broadcast_params(model.state)
+    if A.stepwise:
+        model.set_option('persistent', 0)
+    model.step = 20000                                  # anneal = tanh(2): the KL backward is live
+    ids = torch.as_tensor(synth.batch(B, S, CFG['dim_tgt'], seed=rank)).to(model.device)   # FULL batch, resident in HBM
+    n_glob, b_glob = float(world * B * (S + 1)), float(world * B)
+
+    def one(i):
+        if dp:
+            dp.train_step(ids, ids, n_glob, b_glob, seed=1000 * rank + i)
+        else:
+            model.train_step(ids, ids, seed=i)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(A.warmup):
+        one(i)
+    fence()
+    timing = world == 1
+    if timing:
+        model.set_option('timing', 1)
+    t0 = time.perf_counter()
+    for i in range(A.steps):
+        one(A.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=model.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.losses()
+    assert all(x == x and abs(x) < 1e6 for x in losses), losses
+
+    if rank == 0:
+        out = {
+            "metric": "sentences/sec per ELBO step", "value": world * B * A.steps / dt, "unit": "sentences/sec",
+            "n_gpus": world, "steps": A.steps, "warmup": A.warmup, "ms_per_step": 1e3 * dt / A.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1xMI355X fp32, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
+                                   "FULL synthetic Zipf batches, dim_emb 512, 3 layers, step 20000",
+                       "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
+                       "gru": "stepwise" if A.stepwise else "persistent"},
+            "loss": losses[2],
+        }
+        if timing:
+            tm = model.timing_collect()
+            model.set_option('timing', 0)
+            total_ms = 1e3 * dt
+            name, (ms, n, fl) = max(tm.items(), key=lambda kv: kv[1][0])
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                               "launches_per_step": n / A.steps, "avg_launch_ms": ms / max(n, 1),
+                               "share_of_step": ms / total_ms,
+                               "classes": {k: {"ms_per_step": v[0] / A.steps, "launches_per_step": v[1] / A.steps,
+                                               "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0)} for k, v in tm.items()}}
+            if not A.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

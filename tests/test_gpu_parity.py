@@ -196,5 +196,6 @@ def test_random_draws_are_seeded_and_sane():
     b = m.losses()
     m.forward_backward(ids, ids, seed=12)
     c = m.losses()
-    assert a[0] == b[0] and a[1] == b[1]
-    assert a[0] != c[0]
+    # the loss sums are accumulated with float atomics: equal up to summation order
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(a[1])
+    assert abs(a[0] - c[0]) > 1e-4 * abs(a[0])
