@@ -33,6 +33,12 @@ __device__ __forceinline__ int kperm(int ks, int kh)
     return 4 * ks + kh;
 }
 
+// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms", first table row): every exchanged byte is
+// stored write-through (sc1) and loaded with sc1 loads (L1 bypass); each storing wave drains its
+// stores (vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the group counter with an
+// agent-scope atomic; the consumer polls that counter with a relaxed agent-scope (sc1) load from one
+// lane and releases its workgroup through a barrier.  No cache-wide fence is involved: an agent
+// release would write back every dirty L2 line of the XCD (the saved gates) on every step.
 __device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, int* err)
 {
     if (threadIdx.x == 0) {
@@ -48,9 +54,8 @@ __device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, int* 
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler ordering only
     __syncthreads();
 }
 
@@ -58,11 +63,27 @@ __device__ __forceinline__ void group_publish(unsigned* ctr)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte sc1 (agent-coherent, L1-bypassing) load through a raw buffer descriptor
+__device__ __forceinline__ float4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float load4_sc1(const float* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store4_sc1(float* p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, -1, 0x00020000);
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -104,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gate * 16 + gn];
 
+    const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
     int buf = 0;
     for (int p = a.p_begin; p < a.p_end; ++p) {
         if (p > a.p_begin) group_wait(ctr, (unsigned)(HT * (p - a.p_begin)), a.err);
@@ -113,27 +135,27 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (rb + 16 * c >= row_end) break;           // wave uniform
-                const int row = rb + 16 * c + n;
-                const bool ok = row < B;
-                const float* hsrc = nullptr;
-                if (ok) {
-                    if (p == 0) hsrc = J.h0 ? J.h0 + (size_t)row * D : nullptr;
-                    else {
-                        int pp = pos_map(p - 1, J.reverse ? a.lens[row] : 0, J.reverse);
-                        hsrc = J.hs + ((size_t)pp * B + row) * a.ldh;
-                    }
+                const int row = min(rb + 16 * c + n, B - 1);   // clamped: rows >= B are never stored
+                unsigned aoff = 0; bool have = true;
+                if (p == 0) { have = J.h0 != nullptr; aoff = (unsigned)((size_t)row * D * 4); }
+                else {
+                    int pp = pos_map(p - 1, J.reverse ? a.lens[row] : 0, J.reverse);
+                    aoff = (unsigned)((((size_t)pp * B + row) * a.ldh) * 4);
                 }
+                const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
                 float av[KS];
                 if (KS % 4 == 0) {
 #pragma unroll
                     for (int q = 0; q < KS / 4; ++q) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (hsrc) v = *reinterpret_cast<const float4*>(hsrc + wave * 4 * KS + 16 * q + 4 * kh);
+                        if (have) v = load16_sc1(rs, aoff + (wave * 4 * KS + 16 * q + 4 * kh) * 4);
                         av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
                     }
                 } else {
+                    const float* hsrc = (p == 0) ? J.h0 : J.hs;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) av[ks] = hsrc ? hsrc[wave * 4 * KS + kperm<KS>(ks, kh)] : 0.f;
+                    for (int ks = 0; ks < KS; ++ks)
+                        av[ks] = have ? load4_sc1(hsrc + aoff / 4 + wave * 4 * KS + kperm<KS>(ks, kh)) : 0.f;
                 }
                 f32x4 acc[3];
 #pragma unroll
@@ -167,13 +189,13 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 if (p == 0) { if (J.h0) hprev = J.h0[(size_t)row * D + j]; }
                 else {
                     int pp = pos_map(p - 1, len, J.reverse);
-                    hprev = J.hs[((size_t)pp * B + row) * a.ldh + j];
+                    hprev = load4_sc1(J.hs + ((size_t)pp * B + row) * a.ldh + j);
                 }
                 float r = sigmoidf_(gi[0] + gh[0]);
                 float u = sigmoidf_(gi[16] + gh[1]);
                 float nn = tanhf(gi[32] + r * gh[2]);
                 float hnew = (1.f - u) * nn + u * hprev;
-                J.hs[((size_t)pos * B + row) * a.ldh + j] = hnew;
+                store4_sc1(J.hs + ((size_t)pos * B + row) * a.ldh + j, hnew);
                 if (J.sv) {
                     float* sv = J.sv + (((size_t)pos * B + row) * HT + ht) * 64 + gn;
                     sv[0] = r; sv[16] = u; sv[32] = nn; sv[48] = gh[2];
@@ -216,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     const int j = ht * 16 + gn;
     const bool want_dh0 = (J.dh0 != nullptr) && a.p_begin == 0;
     const int p_last = want_dh0 ? -1 : a.p_begin;       // p == -1: only dh0 = carry + dgh_0 R'
+    const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
     int buf = 0, done = 0;
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
         if (done > 0) group_wait(ctr, (unsigned)(HT * done), a.err);
@@ -229,23 +252,19 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (have_next) {
-                    const int row = rb + 16 * c + n;
-                    const float* src = nullptr;
-                    if (row < B) {
-                        int pos1 = pos_map(p + 1, J.reverse ? a.lens[row] : 0, J.reverse);
-                        src = J.dgh + ((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS;
-                    }
+                    const int row = min(rb + 16 * c + n, B - 1);
+                    const int pos1 = pos_map(p + 1, J.reverse ? a.lens[row] : 0, J.reverse);
+                    const unsigned aoff = (unsigned)((((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS) * 4);
                     float av[NKS];
                     if (NKS % 4 == 0) {
 #pragma unroll
                         for (int q = 0; q < NKS / 4; ++q) {
-                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (src) v = *reinterpret_cast<const float4*>(src + 16 * q + 4 * kh);
+                            float4 v = load16_sc1(rs_dgh, aoff + (16 * q + 4 * kh) * 4);
                             av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
                         }
                     } else {
 #pragma unroll
-                        for (int ks = 0; ks < NKS; ++ks) av[ks] = src ? src[kperm<NKS>(ks, kh)] : 0.f;
+                        for (int ks = 0; ks < NKS; ++ks) av[ks] = load4_sc1(J.dgh + aoff / 4 + kperm<NKS>(ks, kh));
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks)
@@ -276,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 float dr = dn * hn * r * (1.f - r);
                 float* dgi = J.dgi + rix * a.ldg + ht * 48 + gn;
                 float* dgh = J.dgh + rix * a.ldg + ht * 48 + gn;
+                store4_sc1(dgh, dr); store4_sc1(dgh + 16, du); store4_sc1(dgh + 32, dn * r);   // exchanged
                 dgi[0] = dr; dgi[16] = du; dgi[32] = dn;
-                dgh[0] = dr; dgh[16] = du; dgh[32] = dn * r;
                 *carryp = dH * u;
             }
         }

@@ -31,13 +31,26 @@ B, S = 256, 64
 PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md chip table
 
 
+def host_cores():
+    """cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU
+    box shows 256 logical CPUs but grants 16; oversubscribing them makes torch-CPU crawl)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sample_b=32, steps=2):
     import numpy as np
     import torch
     from argsim_amd import synth
     from oracle import vae_numpy as vn
     from oracle import vae_torch as vt
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = vn.make_cfg(**CFG)
     P = vn.init_params(cfg, 0)

@@ -199,3 +199,31 @@ def test_random_draws_are_seeded_and_sane():
     # the loss sums are accumulated with float atomics: equal up to summation order
     assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(a[1])
     assert abs(a[0] - c[0]) > 1e-4 * abs(a[0])
+
+
+def test_bench_scale_persistent_equals_stepwise():
+    """BASELINE configs[1] geometry (B=256, S=64, D=512: 512 co-resident workgroups per GRU launch): the
+    persistent kernels' in-launch hand-offs must reproduce the one-launch-per-step results bit for bit
+    on the forward (z, per-token CE), and the gradients up to float-atomic summation order."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=3, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    ids = synth.batch(256, 64, 8192, ragged=True, seed=5)
+    m.step = 20000
+    res = {}
+    for mode in (1, 0, 1):
+        m.set_option('persistent', mode)
+        z = m.encode(ids)
+        ev = m.eval(ids, ids)
+        m.forward_backward(ids, ids, seed=9)
+        g = m.grads.clone()
+        res.setdefault(mode, []).append((z, ev, g))
+    (z1, e1, g1), (z0, e0, g0), (z2, e2, g2) = res[1][0], res[0][0], res[1][1]
+    assert np.array_equal(z1, z0) and np.array_equal(z1, z2)
+    for a, b in zip(e1, e0):
+        assert np.array_equal(a, b)
+    for a, b in zip(e1, e2):
+        assert np.array_equal(a, b)
+    import torch
+    d = (g1 - g0).norm() / g0.norm()
+    assert float(d) < 1e-5, float(d)
