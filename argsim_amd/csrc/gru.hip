@@ -59,12 +59,50 @@ __device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, int* 
     __syncthreads();
 }
 
-__device__ __forceinline__ void group_publish(unsigned* ctr)
+__device__ __forceinline__ void group_publish(unsigned* ctr, bool fast)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        // fast: the whole group sits on one XCD, whose L2 is the coherence point -> L2 atomic, no sc1
+        if (fast) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
+
+// Same-XCD detection (speed only).  Every workgroup of a group publishes the id of the XCD it runs
+// on through the placement-independent sc1 protocol; if all HT ids agree the group exchanges its
+// per-step data through that XCD's L2 (plain stores, L2 atomics, L1-bypassing loads) instead of
+// write-through to the memory side.  All members read the same HT words, so they all take the same
+// decision; a group spread over several XCDs simply keeps the sc1 protocol.
+__device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, int ht, int HT, int* err, int force_slow)
+{
+    __shared__ int s_fast;
+    if (threadIdx.x == 0) {
+        const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
+        __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0; bool ok = true;
+        while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HT) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false; break;
+            }
+        }
+        bool same = ok && !force_slow;
+        for (int i = 0; i < HT && same; ++i)
+            same = __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my + 1u;
+        s_fast = same ? 1 : 0;
+    }
+    __syncthreads();
+    return s_fast != 0;
+}
+
+// diagnostic phase stamps (ablate bit 32): 100 MHz real-time counter deltas summed per workgroup
+#define AVAE_STAMP(i) do { if (ab & 32) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 16-byte sc1 (agent-coherent, L1-bypassing) load through a raw buffer descriptor
@@ -87,11 +125,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p)
 }
 
 // ------------------------------------------------------------------------------ forward
+// Per step and workgroup:  (1) issue the loads that do not depend on the exchange (gi) ; (2) wait for
+// the group's h_{p-1} ; (3) issue ALL A-operand loads of the (up to) 32 rows, then the MFMAs ;
+// (4) K-split partial sums and the workgroup's own h_{p-1} slice meet in LDS ; (5) gate math ;
+// (6) store h_p write-through and publish ; (7) only then store what nobody waits for (saved gates).
 template <int KS>   // D = 16*KS
 __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 {
     constexpr int D = 16 * KS, HT = KS;
     __shared__ __attribute__((aligned(16))) float part[2][2][4][3][256];   // [buf][chunk][wave][gate][lane*4+reg]
+    __shared__ __attribute__((aligned(16))) float hps[2][2][16][16];       // [buf][chunk][row][unit] own h_{p-1} slice
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kh = lane >> 4;
@@ -103,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     const int B = a.B;
     const int row_beg = g * a.rows_per_group;
     const int row_end = min(B, row_beg + a.rows_per_group);
+    const int ab = a.ablate;
 
     // weights -> registers, MFMA B-operand order: B[k][n] = R'[ht*48 + gate*16 + n][k]
     float w[3][KS];
@@ -121,89 +165,155 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
         }
     }
     const int gn = tid & 15, gr = tid >> 4;        // gate-phase item: unit gn, row gr (+16 per chunk)
+    const int j = ht * 16 + gn;
     float bR[3];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gate * 16 + gn];
+    // which wave / register group holds this workgroup's own 16 columns of h_{p-1}
+    constexpr int WK = 4 * KS;                                  // K range per wave
+    const int own_wave = (KS % 4 == 0) ? (ht * 16) / WK : -1;
+    const int own_q = (KS % 4 == 0) ? ((ht * 16) % WK) / 16 : 0;
 
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
+    bool fast = false;
+    if (a.p_end - a.p_begin > 1 && !(ab & 16))
+        fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
     int buf = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_begin; p < a.p_end; ++p) {
-        if (p > a.p_begin) group_wait(ctr, (unsigned)(HT * (p - a.p_begin)), a.err);
-
         for (int rb = row_beg; rb < row_end; rb += 32, buf ^= 1) {
-            // ---- MFMA phase: partial gh = h_{p-1}[rows, wave's K range] x R'^T
+            AVAE_STAMP(7);
+            // (1) exchange-independent loads of the gate phase
+            float gi[2][3]; int gpos[2]; bool gok[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                if (rb + 16 * c >= row_end) break;           // wave uniform
-                const int row = min(rb + 16 * c + n, B - 1);   // clamped: rows >= B are never stored
-                unsigned aoff = 0; bool have = true;
-                if (p == 0) { have = J.h0 != nullptr; aoff = (unsigned)((size_t)row * D * 4); }
+                const int row = rb + 16 * c + gr;
+                gok[c] = row < row_end;
+                gpos[c] = 0;
+                gi[c][0] = gi[c][1] = gi[c][2] = 0.f;
+                if (gok[c]) {
+                    gpos[c] = pos_map(p, J.reverse ? a.lens[row] : 0, J.reverse);
+                    if (!(ab & 2)) {
+                        const float* gp = J.gi + ((size_t)gpos[c] * B + row) * a.ldg + ht * 48 + gn;
+                        gi[c][0] = gp[0]; gi[c][1] = gp[16]; gi[c][2] = gp[32];
+                    }
+                }
+            }
+            // (2) the group's h_{p-1} must be complete
+            AVAE_STAMP(0);
+            if (rb == row_beg && p > a.p_begin && !(ab & 16)) group_wait(ctr, (unsigned)(HT * (p - a.p_begin)), a.err);
+            AVAE_STAMP(1);
+
+            // (3) A operand: every load of both chunks first, then the MFMAs
+            float av[2][KS];
+            const bool c1 = rb + 16 < row_end;                       // second chunk present (uniform)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c == 1 && !c1) break;
+                const int row = min(rb + 16 * c + n, B - 1);         // clamped: rows >= B are never stored
+                unsigned aoff = 0; bool have = !(ab & 1);
+                if (p == 0) { have = have && J.h0 != nullptr; aoff = (unsigned)((size_t)row * D * 4); }
                 else {
                     int pp = pos_map(p - 1, J.reverse ? a.lens[row] : 0, J.reverse);
                     aoff = (unsigned)((((size_t)pp * B + row) * a.ldh) * 4);
                 }
                 const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
-                float av[KS];
                 if (KS % 4 == 0) {
 #pragma unroll
                     for (int q = 0; q < KS / 4; ++q) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (have) v = load16_sc1(rs, aoff + (wave * 4 * KS + 16 * q + 4 * kh) * 4);
-                        av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+                        if (have) v = load16_sc1(rs, aoff + (wave * WK + 16 * q + 4 * kh) * 4);
+                        av[c][4 * q + 0] = v.x; av[c][4 * q + 1] = v.y; av[c][4 * q + 2] = v.z; av[c][4 * q + 3] = v.w;
                     }
                 } else {
                     const float* hsrc = (p == 0) ? J.h0 : J.hs;
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
-                        av[ks] = have ? load4_sc1(hsrc + aoff / 4 + wave * 4 * KS + kperm<KS>(ks, kh)) : 0.f;
+                        av[c][ks] = have ? load4_sc1(hsrc + aoff / 4 + wave * WK + kperm<KS>(ks, kh)) : 0.f;
                 }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c == 1 && !c1) break;
                 f32x4 acc[3];
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(ab & 1)) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int gate = 0; gate < 3; ++gate)
-                        acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], w[gate][ks], acc[gate], 0, 0, 0);
+                        for (int gate = 0; gate < 3; ++gate)
+                            acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][ks], w[gate][ks], acc[gate], 0, 0, 0);
+                }
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate)
                     *reinterpret_cast<f32x4*>(&part[buf][c][wave][gate][lane * 4]) = acc[gate];
+                // (4) own h_{p-1} slice -> LDS: lane (kh*16 + r) holds h[r][k = wave*WK + 16q + 4kh + e]
+                if (KS % 4 == 0) {
+                    if (wave == own_wave) {
+#pragma unroll
+                        for (int q = 0; q < KS / 4; ++q)
+                            if (q == own_q)
+                                *reinterpret_cast<float4*>(&hps[buf][c][n][4 * kh]) =
+                                    make_float4(av[c][4 * q], av[c][4 * q + 1], av[c][4 * q + 2], av[c][4 * q + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        int k = wave * WK + kperm<KS>(ks, kh) - ht * 16;
+                        if (k >= 0 && k < 16) hps[buf][c][n][k] = av[c][ks];
+                    }
+                }
             }
+            AVAE_STAMP(2);
             __syncthreads();
-            // ---- gate phase: 32 rows x 16 units, two items per thread
+            AVAE_STAMP(3);
+            // (5) gate math: 32 rows x 16 units, two items per thread
+            float o_r[2], o_u[2], o_n[2], o_hn[2], o_hp[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                if (!gok[c]) continue;
                 const int row = rb + 16 * c + gr;
-                if (row >= row_end) continue;
-                const int len = J.reverse ? a.lens[row] : 0;
-                const int pos = pos_map(p, len, J.reverse);
-                const int j = ht * 16 + gn;
                 const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
                 float gh[3];
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate)
                     gh[gate] = bR[gate] + ((part[buf][c][0][gate][pidx] + part[buf][c][1][gate][pidx]) +
                                            (part[buf][c][2][gate][pidx] + part[buf][c][3][gate][pidx]));
-                const float* gi = J.gi + ((size_t)pos * B + row) * a.ldg + ht * 48 + gn;
-                float hprev = 0.f;
-                if (p == 0) { if (J.h0) hprev = J.h0[(size_t)row * D + j]; }
-                else {
-                    int pp = pos_map(p - 1, len, J.reverse);
-                    hprev = load4_sc1(J.hs + ((size_t)pp * B + row) * a.ldh + j);
-                }
-                float r = sigmoidf_(gi[0] + gh[0]);
-                float u = sigmoidf_(gi[16] + gh[1]);
-                float nn = tanhf(gi[32] + r * gh[2]);
-                float hnew = (1.f - u) * nn + u * hprev;
-                store4_sc1(J.hs + ((size_t)pos * B + row) * a.ldh + j, hnew);
-                if (J.sv) {
-                    float* sv = J.sv + (((size_t)pos * B + row) * HT + ht) * 64 + gn;
-                    sv[0] = r; sv[16] = u; sv[32] = nn; sv[48] = gh[2];
-                }
-                if (J.hp) J.hp[((size_t)pos * B + row) * D + j] = hprev;
+                const float hprev = hps[buf][c][gr][gn];
+                float r, u, nn;
+                if (ab & 8) { r = 0.5f + 0.1f * (gi[c][0] + gh[0]); u = 0.5f + 0.1f * (gi[c][1] + gh[1]); nn = 0.1f * (gi[c][2] + r * gh[2]); }
+                else { r = sigmoidf_(gi[c][0] + gh[0]); u = sigmoidf_(gi[c][1] + gh[1]); nn = tanhf(gi[c][2] + r * gh[2]); }
+                const float hnew = (1.f - u) * nn + u * hprev;
+                // (6) exchanged store first
+                float* hdst = J.hs + ((size_t)gpos[c] * B + row) * a.ldh + j;
+                if (fast) *hdst = hnew; else store4_sc1(hdst, hnew);
+                o_r[c] = r; o_u[c] = u; o_n[c] = nn; o_hn[c] = gh[2]; o_hp[c] = hprev;
             }
+            AVAE_STAMP(4);
+            if (rb + 32 >= row_end && p + 1 < a.p_end && !(ab & 16)) group_publish(ctr, fast);
+            AVAE_STAMP(5);
+            // (7) stores nobody in this launch waits for
+            if (!(ab & 4)) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (!gok[c]) continue;
+                    const size_t rix = (size_t)gpos[c] * B + (rb + 16 * c + gr);
+                    if (J.sv) {
+                        float* sv = J.sv + (rix * HT + ht) * 64 + gn;
+                        sv[0] = o_r[c]; sv[16] = o_u[c]; sv[32] = o_n[c]; sv[48] = o_hn[c];
+                    }
+                    if (J.hp) J.hp[rix * D + j] = o_hp[c];
+                }
+            }
+            AVAE_STAMP(6);
         }
-        if (p + 1 < a.p_end) group_publish(ctr);
+    }
+    if ((ab & 32) && tid == 0 && a.stamps) {
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, ph[i]);
+        atomicAdd(a.stamps + 8, (unsigned long long)(a.p_end - a.p_begin));
+        atomicAdd(a.stamps + 9, (unsigned long long)(fast ? 1 : 0));
+        atomicAdd(a.stamps + 10, 1ULL);
     }
 }
 
@@ -211,11 +321,14 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 // step p (descending):  dH_p = dh_out[p] + dH_{p+1} u_{p+1} + dgh_{p+1} R'
 //   dn = dH (1-u)(1-n^2)   du = dH (h_{p-1} - n) u (1-u)   dr = dn hn r (1-r)
 //   dgi = [dr,du,dn]   dgh = [dr,du,dn r]
+// The bias gradients (column sums of dgi / dgh over all rows and steps) are accumulated in
+// registers across the whole launch and leave through one LDS reduction + 96 float atomics.
 template <int KS>
 __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 {
     constexpr int D = 16 * KS, HT = KS, NKS = 3 * KS;   // wave K range = 3D/4 = 12*KS floats
     __shared__ __attribute__((aligned(16))) float part[2][2][4][256];
+    __shared__ float red[4][16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kh = lane >> 4;
@@ -227,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     const int B = a.B, S = a.S;
     const int row_beg = g * a.rows_per_group;
     const int row_end = min(B, row_beg + a.rows_per_group);
+    const int ab = a.ablate;
 
     // B operand: B[k = c'][n] = R'[c'][ht*16 + n]
     float w[NKS];
@@ -239,41 +353,90 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     const bool want_dh0 = (J.dh0 != nullptr) && a.p_begin == 0;
     const int p_last = want_dh0 ? -1 : a.p_begin;       // p == -1: only dh0 = carry + dgh_0 R'
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
+    float sb_r = 0.f, sb_u = 0.f, sb_n = 0.f, sb_nr = 0.f;   // bias-gradient partial sums
+    bool fast = false;
+    if (a.p_end - 1 > p_last && !(ab & 16))
+        fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
     int buf = 0, done = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
-        if (done > 0) group_wait(ctr, (unsigned)(HT * done), a.err);
         const bool have_next = (p + 1 < S);
-
         for (int rb = row_beg; rb < row_end; rb += 32, buf ^= 1) {
+            AVAE_STAMP(7);
+            // (1) exchange-independent loads of the gate phase
+            float s_r[2], s_u[2], s_n[2], s_hn[2], s_hp[2], s_do[2]; int rix[2]; bool gok[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                if (rb + 16 * c >= row_end) break;
-                f32x4 acc[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (have_next) {
-                    const int row = min(rb + 16 * c + n, B - 1);
-                    const int pos1 = pos_map(p + 1, J.reverse ? a.lens[row] : 0, J.reverse);
-                    const unsigned aoff = (unsigned)((((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS) * 4);
-                    float av[NKS];
-                    if (NKS % 4 == 0) {
-#pragma unroll
-                        for (int q = 0; q < NKS / 4; ++q) {
-                            float4 v = load16_sc1(rs_dgh, aoff + (16 * q + 4 * kh) * 4);
-                            av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int ks = 0; ks < NKS; ++ks) av[ks] = load4_sc1(J.dgh + aoff / 4 + kperm<NKS>(ks, kh));
+                const int row = rb + 16 * c + gr;
+                gok[c] = row < row_end && p >= 0;
+                rix[c] = 0; s_r[c] = s_u[c] = s_n[c] = s_hn[c] = s_hp[c] = s_do[c] = 0.f;
+                if (gok[c]) {
+                    const int pos = pos_map(p, J.reverse ? a.lens[row] : 0, J.reverse);
+                    rix[c] = pos * B + row;
+                    if (!(ab & 2)) {
+                        const float* sv = J.sv + ((size_t)rix[c] * HT + ht) * 64 + gn;
+                        s_r[c] = sv[0]; s_u[c] = sv[16]; s_n[c] = sv[32]; s_hn[c] = sv[48];
+                        s_hp[c] = J.hp[(size_t)rix[c] * D + j];
+                        if (J.dh_out) s_do[c] = J.dh_out[(size_t)rix[c] * a.ldh + j];
                     }
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks)
-                        acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], w[ks], acc[ks & 3], 0, 0, 0);
                 }
-                f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-                *reinterpret_cast<f32x4*>(&part[buf][c][wave][lane * 4]) = s;
             }
+            AVAE_STAMP(0);
+            if (rb == row_beg && done > 0 && !(ab & 16)) group_wait(ctr, (unsigned)(HT * done), a.err);
+            AVAE_STAMP(1);
+
+            const bool c1 = rb + 16 < row_end;
+            // A operand = dgh_{p+1} rows (K = 3D, this wave's quarter).  Two half-chunk register
+            // buffers in flight: the loads of the next half are issued before the MFMAs of the current.
+            constexpr int NH = (NKS % 16 == 0) ? 4 : ((NKS % 8 == 0) ? 2 : 1);   // pieces per chunk
+            constexpr int HK = NKS / NH;                                          // MFMA steps per piece
+            float hv[2][HK];
+            auto load_half = [&](float (&dst)[HK], int c, int hf) {
+                const int row = min(rb + 16 * c + n, B - 1);
+                const int pos1 = pos_map(p + 1, J.reverse ? a.lens[row] : 0, J.reverse);
+                const unsigned aoff = (unsigned)((((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS) * 4);
+                if (NKS % 4 == 0) {
+#pragma unroll
+                    for (int q = 0; q < HK / 4; ++q) {
+                        float4 v = load16_sc1(rs_dgh, aoff + (16 * (q + hf * (HK / 4)) + 4 * kh) * 4);
+                        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < HK; ++ks) dst[ks] = load4_sc1(J.dgh + aoff / 4 + kperm<NKS>(ks + hf * HK, kh));
+                }
+            };
+            const bool do_mm = have_next && !(ab & 1);
+            const int nstage = (c1 ? 2 : 1) * NH;                     // (chunk, half) stages, uniform
+            if (do_mm) { load_half(hv[0], 0, 0); if (nstage > 1) load_half(hv[1], 1 / NH, 1 % NH); }
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int hf = 0; hf < NH; ++hf) {
+                    const int st = c * NH + hf;                     // compile-time after unrolling
+                    if (st < nstage) {
+                        if (hf == 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        if (do_mm) {
+#pragma unroll
+                            for (int ks = 0; ks < HK; ++ks)
+                                acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[st & 1][ks], w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
+                            if (st + 2 < nstage) load_half(hv[st & 1], (st + 2) / NH, (st + 2) % NH);
+                        }
+                        if (hf == NH - 1) {
+                            f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                            *reinterpret_cast<f32x4*>(&part[buf][c][wave][lane * 4]) = s;
+                        }
+                    }
+                }
+            }
+            AVAE_STAMP(2);
             __syncthreads();
+            AVAE_STAMP(3);
+            float o_dr[2], o_du[2], o_dn[2], o_car[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int row = rb + 16 * c + gr;
@@ -283,28 +446,56 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 float* carryp = J.carry + (size_t)row * D + j;
                 if (have_next) carried += *carryp;
                 if (p < 0) { J.dh0[(size_t)row * D + j] = carried; continue; }
-                const int len = J.reverse ? a.lens[row] : 0;
-                const int pos = pos_map(p, len, J.reverse);
-                const size_t rix = (size_t)pos * B + row;
-                float dH = carried + (J.dh_out ? J.dh_out[rix * a.ldh + j] : 0.f);
-                const float* sv = J.sv + (rix * HT + ht) * 64 + gn;
-                float r = sv[0], u = sv[16], nn = sv[32], hn = sv[48];
-                float hprev = J.hp[rix * D + j];
-                float dn = dH * (1.f - u) * (1.f - nn * nn);
-                float du = dH * (hprev - nn) * u * (1.f - u);
-                float dr = dn * hn * r * (1.f - r);
-                float* dgi = J.dgi + rix * a.ldg + ht * 48 + gn;
-                float* dgh = J.dgh + rix * a.ldg + ht * 48 + gn;
-                store4_sc1(dgh, dr); store4_sc1(dgh + 16, du); store4_sc1(dgh + 32, dn * r);   // exchanged
-                dgi[0] = dr; dgi[16] = du; dgi[32] = dn;
-                *carryp = dH * u;
+                const float dH = carried + s_do[c];
+                const float r = s_r[c], u = s_u[c], nn = s_n[c];
+                const float dn = dH * (1.f - u) * (1.f - nn * nn);
+                const float du = dH * (s_hp[c] - nn) * u * (1.f - u);
+                const float dr = dn * s_hn[c] * r * (1.f - r);
+                float* dgh = J.dgh + (size_t)rix[c] * a.ldg + ht * 48 + gn;
+                if (fast) { dgh[0] = dr; dgh[16] = du; dgh[32] = dn * r; }                        // exchanged
+                else { store4_sc1(dgh, dr); store4_sc1(dgh + 16, du); store4_sc1(dgh + 32, dn * r); }
+                o_dr[c] = dr; o_du[c] = du; o_dn[c] = dn; o_car[c] = dH * u;
+                sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r;
+            }
+            AVAE_STAMP(4);
+            if (rb + 32 >= row_end && p > p_last && !(ab & 16)) group_publish(ctr, fast);
+            AVAE_STAMP(5);
+            if (p >= 0) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int row = rb + 16 * c + gr;
+                    if (row >= row_end) continue;
+                    J.carry[(size_t)row * D + j] = o_car[c];
+                    if (!(ab & 4)) {
+                        float* dgi = J.dgi + (size_t)rix[c] * a.ldg + ht * 48 + gn;
+                        dgi[0] = o_dr[c]; dgi[16] = o_du[c]; dgi[32] = o_dn[c];
+                    }
+                }
             }
         }
-        if (p > p_last) group_publish(ctr);
+    }
+    if ((ab & 32) && tid == 0 && a.stamps) {
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + 16 + i, ph[i]);
+        atomicAdd(a.stamps + 16 + 8, (unsigned long long)(a.p_end - a.p_begin));
+        atomicAdd(a.stamps + 16 + 9, (unsigned long long)(fast ? 1 : 0));
+        atomicAdd(a.stamps + 16 + 10, 1ULL);
+    }
+    // bias gradients: reduce the 16 row-lanes of the workgroup, then one atomic per (gate, unit)
+    if (J.dbW || J.dbR) {
+        if (tid < 64) red[tid >> 4][tid & 15] = 0.f;
+        __syncthreads();
+        atomicAdd(&red[0][gn], sb_r); atomicAdd(&red[1][gn], sb_u); atomicAdd(&red[2][gn], sb_n); atomicAdd(&red[3][gn], sb_nr);
+        __syncthreads();
+        if (tid < 48) {
+            const int gate = tid >> 4, u = tid & 15;
+            if (J.dbW) atomicAdd(J.dbW + ht * 48 + gate * 16 + u, red[gate][u]);
+            if (J.dbR) atomicAdd(J.dbR + ht * 48 + gate * 16 + u, red[gate == 2 ? 3 : gate][u]);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------ launchers
+constexpr int kGruSyncWords = 64 + 64 + 1536;   // step counters, detection counters, XCD ids (njobs*G*HT)
 bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 512; }
 
 template <bool FWD>
@@ -339,7 +530,7 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
-        e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * 64, st); if (e != hipSuccess) return e;
+        e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
         return launch<true>(st, a, grid);
     }
     for (int p = a.p_begin; p < a.p_end; ++p) {
@@ -353,7 +544,7 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
-        e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * 64, st); if (e != hipSuccess) return e;
+        e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
         return launch<false>(st, a, grid);
     }
     // one launch per step (descending); the dh0 tail (p = -1) rides with p = 0 only in the
@@ -363,7 +554,7 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
         if (p == 0) {
             // run step 0 without the tail, then the tail alone
             GruArgs c = b; for (int i = 0; i < c.njobs; ++i) c.job[i].dh0 = nullptr;
-            e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * 64, st); if (e != hipSuccess) return e;
+            e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
             e = launch<false>(st, c, grid); if (e != hipSuccess) return e;
             bool any = false; for (int i = 0; i < a.njobs; ++i) any |= a.job[i].dh0 != nullptr;
             if (any) {

@@ -46,6 +46,8 @@ struct GruJob {
     float* dgh;           // (S,B,ldg)
     float* dh0;           // (B,D) or nullptr
     float* carry;         // (B,D) scratch: dH_{p+1} * u_{p+1}
+    float* dbW;           // (3D) G16 += column sums of dgi (or nullptr)
+    float* dbR;           // (3D) G16 += column sums of dgh (or nullptr)
 };
 struct GruArgs {
     GruJob job[kMaxGruJobs];
@@ -54,8 +56,11 @@ struct GruArgs {
     int G;                // batch groups per job
     int rows_per_group;   // multiple of 16
     int p_begin, p_end;   // steps [p_begin, p_end) of this launch
-    unsigned* counters;   // njobs*G words, zeroed by the launcher
+    unsigned* counters;   // 1664 words (step counters | detection counters | XCD ids), zeroed by the launcher
     int* err;             // device error word (set on spin timeout)
+    unsigned long long* stamps;   // 32 words of diagnostic phase sums (ablate bit 32) or nullptr
+    int force_slow;       // 1: never use the same-XCD L2 fast path
+    int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);

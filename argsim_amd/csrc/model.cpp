@@ -45,6 +45,7 @@ struct avae_ctx {
     int64_t step = 0;
     avae_grad_hook hook = nullptr; void* hook_user = nullptr;
     int persistent = 1;
+    int gru_ablate = 0, gru_force_slow = 0;
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
     std::vector<GruP> enc;     // per layer: W = [fwd;bwd] (6D,In), R = [fwd;bwd], bW (6D), bR (6D)
@@ -246,7 +247,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw;
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.gi = w.e_gi[i] + d * 3 * D;
@@ -287,7 +288,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw;
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.gi = w.d_gi[i]; j.R = h->P + p.R; j.bR = h->P + p.bR;
         j.h0 = state_in + state_stride * i;
@@ -366,18 +367,17 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw;
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
         j.dh0 = w.dh0 + (size_t)i * B * D; j.carry = w.carry;
+        j.dbW = G + p.bW; j.dbR = G + p.bR;
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_CHECK(gru_backward(st, a, h->persistent != 0)); }
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt));
-        AV_CHECK(colsum(st, w.dgi_d, rt, 3 * D, 3 * D, G + p.bW, nullptr));
         AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
-        AV_CHECK(colsum(st, w.dgh_d, rt, 3 * D, 3 * D, G + p.bR, nullptr));
         float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
         AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D));
         cur ^= 1;
@@ -409,21 +409,20 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw;
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
             j.dh_out = w.dhs[cur] + d * D; j.dgi = w.dgi_e + d * 3 * D; j.dgh = w.dgh_e + d * 3 * D;
             j.dh0 = nullptr; j.carry = w.carry + (size_t)d * B * D;
+            j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
         { Timed t(h, 2, 2.0 * 2 * (Ss - 1) * (double)B * D * 3 * D);
           AV_CHECK(gru_backward(st, a, h->persistent != 0)); }
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
-        AV_CHECK(colsum(st, w.dgi_e, rs, 6 * D, 6 * D, G + p.bW, nullptr));
         for (int d = 0; d < 2; ++d)
             AV_TRY(gemm_tn_grad(h, w.dgh_e + d * 3 * D, 6 * D, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs));
-        AV_CHECK(colsum(st, w.dgh_e, rs, 6 * D, 6 * D, G + p.bR, nullptr));
         float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
         AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D));
         cur ^= 1;
@@ -544,11 +543,11 @@ int avae_create(const avae_config* cfg, int device, avae_handle* out)
     build_params(h);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->losses), 64 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->errw), 64 * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counters), 64 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->errw), 128 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counters), 2048 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(h->losses, 0, 64 * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(h->errw, 0, 64 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(h->counters, 0, 64 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->errw, 0, 128 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->counters, 0, 2048 * sizeof(unsigned));
     if (e != hipSuccess) { g_create_err = std::string("hip init failed: ") + hipGetErrorString(e); delete h; return 1; }
     h->acc = h->losses + 8;
     *out = h;
@@ -640,6 +639,8 @@ int avae_set_option(avae_handle h, const char* key, int value)
 {
     if (!h || !key) return 1;
     if (!strcmp(key, "persistent")) { h->persistent = value; return 0; }
+    if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
+    if (!strcmp(key, "gru_ablate")) { h->gru_ablate = value; return 0; }
     if (!strcmp(key, "timing")) { h->timing = value; h->stamps_used = 0; return 0; }
     return fail(h, "unknown option");
 }
@@ -657,6 +658,15 @@ int avae_timing_collect(avae_handle h, double* out)
         out[3 * c] += ms; out[3 * c + 1] += 1.0; out[3 * c + 2] += h->stamps[i].flops;
     }
     h->stamps_used = 0;
+    return 0;
+}
+// diagnostic: reads and clears the 32 GRU phase-stamp words (option gru_ablate bit 32)
+int avae_debug_stamps(avae_handle h, unsigned long long* out)
+{
+    if (!h || !out) return 1;
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    AV_CHECK(hipMemcpy(out, h->errw + 16, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    AV_CHECK(hipMemset(h->errw + 16, 0, 32 * sizeof(unsigned long long)));
     return 0;
 }
 // test hook: the MFMA GEMM on caller buffers (see kernels.h for the operand conventions)
