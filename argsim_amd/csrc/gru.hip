@@ -9,21 +9,35 @@
 // Decomposition.  One workgroup (4 waves) owns 16 hidden units (x3 gates) of one job
 // (= one layer-direction) for one batch group.  Its 48xD slice of R lives in REGISTERS for
 // the whole launch, already in v_mfma_f32_16x16x4_f32 B-operand order (3*D/16 VGPRs per lane);
-// the four waves split K = D, partial sums meet in LDS, then 256 threads do the gate math.
-// Per step a workgroup reads only its group's h_{t-1} rows (A operand) and publishes its
-// 16-column slice of h_t.  Workgroups that share a batch group synchronise through one
-// monotonic counter per (job, group) with agent-scope release/acquire -- never a grid
-// barrier.  blockIdx % G selects the group, so under round-robin dispatch a group's
-// workgroups share an XCD (speed only; correctness is placement independent).
-// Every spin is bounded; on time-out the error word is set and all waits fall through.
+// the four waves split K, partial sums meet in LDS, then 256 threads do the gate math.
+// Per step a workgroup reads only its group's h_{t-1} rows (A operand) and writes its
+// 16-column slice of h_t.
+//
+// Exchange between the workgroups of a group ("the data is the flag", MI355X_MICROARCH.md
+// R2 granules with an in-band tag): the launcher fills the exchanged buffer (hs forward, dgh
+// backward) with a sentinel bit pattern that the arithmetic never produces (0xFFFFFFFF, a NaN with
+// every payload bit set; h is bounded by 1 and hardware NaNs are canonical).  Each 4-byte element
+// is written exactly once per launch by ONE store; a consumer wave loads its A fragment with
+// L1-bypassing (sc1) loads and simply re-loads it until no dword carries the sentinel.  There is no
+// counter, no fence, no store drain and no workgroup barrier on the hand-off.  Stores are
+// write-through (sc1) unless all workgroups of the group were dispatched to one XCD, in which case
+// that XCD's L2 is the coherence point and plain stores suffice (detected at run time with the
+// placement-independent protocol; speed only).  Every spin is bounded; on time-out the error word
+// is set and every wait falls through, so the grid always drains.
 #include "kernels.h"
 
 namespace avae {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kSentinel = 0xFFFFFFFFu;
 
 __device__ __forceinline__ int pos_map(int p, int len, int reverse) { return (reverse && p < len) ? (len - 1 - p) : p; }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (each <= 1 ulp): absolute error ~1e-7, far inside the
+// fp32 parity tolerances, at a fraction of the libm cost that sat on the per-step critical path
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 // k offset (inside one wave's contiguous K range) of MFMA step ks for lane quarter kh
 template <int NKS>
@@ -33,87 +47,16 @@ __device__ __forceinline__ int kperm(int ks, int kh)
     return 4 * ks + kh;
 }
 
-// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms", first table row): every exchanged byte is
-// stored write-through (sc1) and loaded with sc1 loads (L1 bypass); each storing wave drains its
-// stores (vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the group counter with an
-// agent-scope atomic; the consumer polls that counter with a relaxed agent-scope (sc1) load from one
-// lane and releases its workgroup through a barrier.  No cache-wide fence is involved: an agent
-// release would write back every dirty L2 line of the XCD (the saved gates) on every step.
-__device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, int* err)
-{
-    if (threadIdx.x == 0) {
-        unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-        unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0) {
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {   // 2 s
-                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler ordering only
-    __syncthreads();
-}
-
-__device__ __forceinline__ void group_publish(unsigned* ctr, bool fast)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // fast: the whole group sits on one XCD, whose L2 is the coherence point -> L2 atomic, no sc1
-        if (fast) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Same-XCD detection (speed only).  Every workgroup of a group publishes the id of the XCD it runs
-// on through the placement-independent sc1 protocol; if all HT ids agree the group exchanges its
-// per-step data through that XCD's L2 (plain stores, L2 atomics, L1-bypassing loads) instead of
-// write-through to the memory side.  All members read the same HT words, so they all take the same
-// decision; a group spread over several XCDs simply keeps the sc1 protocol.
-__device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, int ht, int HT, int* err, int force_slow)
-{
-    __shared__ int s_fast;
-    if (threadIdx.x == 0) {
-        const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
-        __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        unsigned spins = 0; bool ok = true;
-        while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HT) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false; break;
-            }
-        }
-        bool same = ok && !force_slow;
-        for (int i = 0; i < HT && same; ++i)
-            same = __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my + 1u;
-        s_fast = same ? 1 : 0;
-    }
-    __syncthreads();
-    return s_fast != 0;
-}
-
 // diagnostic phase stamps (ablate bit 32): 100 MHz real-time counter deltas summed per workgroup
 #define AVAE_STAMP(i) do { if (ab & 32) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// 16-byte sc1 (agent-coherent, L1-bypassing) load through a raw buffer descriptor
-__device__ __forceinline__ float4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off)
+__device__ __forceinline__ u32x4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off)
 {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);     // aux 16 = sc1
 }
-__device__ __forceinline__ float load4_sc1(const float* p)
+__device__ __forceinline__ unsigned load4_sc1(const float* p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void store4_sc1(float* p, float v)
 {
@@ -124,15 +67,97 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, -1, 0x00020000);
 }
 
+// bounded spin bookkeeping shared by the data polls: returns true when the wave must give up
+struct SpinGuard {
+    unsigned long long t0 = 0; unsigned n = 0;
+    __device__ __forceinline__ bool expired(int* err)
+    {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++n & 31u) != 0) return false;
+        if (t0 == 0) t0 = __builtin_amdgcn_s_memrealtime();
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {   // 2 s at 100 MHz
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        return false;
+    }
+};
+
+// Loads NQ 16-byte pieces (stride 64 B) of one row per lane and repeats until no dword of the
+// WAVE's fragment equals the sentinel (poll == false: single pass).
+template <int NQ>
+__device__ __forceinline__ void load_frag(float* dst, __amdgpu_buffer_rsrc_t rs, unsigned off, bool poll, int* err)
+{
+    SpinGuard sg;
+    for (;;) {
+        u32x4 v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = load16_sc1(rs, off + 64u * q);
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bad |= (v[q].x == kSentinel) | (v[q].y == kSentinel) | (v[q].z == kSentinel) | (v[q].w == kSentinel);
+        if (!poll || !__any(bad) || sg.expired(err)) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                dst[4 * q + 0] = __uint_as_float(v[q].x); dst[4 * q + 1] = __uint_as_float(v[q].y);
+                dst[4 * q + 2] = __uint_as_float(v[q].z); dst[4 * q + 3] = __uint_as_float(v[q].w);
+            }
+            return;
+        }
+    }
+}
+// scalar-element variant for the small test dimensions (wave K range not a multiple of 16)
+template <int N, int NKS>
+__device__ __forceinline__ void load_frag_scalar(float* dst, const float* base, int ks0, int kh, bool poll, int* err)
+{
+    SpinGuard sg;
+    for (;;) {
+        unsigned v[N]; bool bad = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { v[i] = load4_sc1(base + kperm<NKS>(ks0 + i, kh)); bad |= v[i] == kSentinel; }
+        if (!poll || !__any(bad) || sg.expired(err)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) dst[i] = __uint_as_float(v[i]);
+            return;
+        }
+    }
+}
+
+// Same-XCD detection (speed only): every workgroup of a group publishes the id of the XCD it runs
+// on with the placement-independent sc1 protocol; if all HT ids agree the group's per-step stores
+// may stay in that XCD's L2 (plain stores) instead of being written through to the memory side.
+// All members read the same HT words, so they all take the same decision.
+__device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, int ht, int HT, int* err, int force_slow)
+{
+    __shared__ int s_fast;
+    if (threadIdx.x == 0) {
+        const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
+        __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SpinGuard sg; bool ok = true;
+        while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HT)
+            if (sg.expired(err)) { ok = false; break; }
+        bool same = ok && !force_slow;
+        for (int i = 0; i < HT && same; ++i)
+            same = __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my + 1u;
+        s_fast = same ? 1 : 0;
+    }
+    __syncthreads();
+    return s_fast != 0;
+}
+
 // ------------------------------------------------------------------------------ forward
-// Per step and workgroup:  (1) issue the loads that do not depend on the exchange (gi) ; (2) wait for
-// the group's h_{p-1} ; (3) issue ALL A-operand loads of the (up to) 32 rows, then the MFMAs ;
-// (4) K-split partial sums and the workgroup's own h_{p-1} slice meet in LDS ; (5) gate math ;
-// (6) store h_p write-through and publish ; (7) only then store what nobody waits for (saved gates).
+// Per step and workgroup: (1) issue the loads that do not depend on the exchange (gi);
+// (2) load the A operand = the group's h_{p-1} rows, re-loading until complete; (3) MFMAs;
+// (4) K-split partial sums and the workgroup's own h_{p-1} slice meet in LDS (the only barrier of
+// the step); (5) gate math; (6) store h_p (the exchanged data) first, then the saved gates.
 template <int KS>   // D = 16*KS
 __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 {
     constexpr int D = 16 * KS, HT = KS;
+    constexpr int WK = 4 * KS;                                  // K range per wave
     __shared__ __attribute__((aligned(16))) float part[2][2][4][3][256];   // [buf][chunk][wave][gate][lane*4+reg]
     __shared__ __attribute__((aligned(16))) float hps[2][2][16][16];       // [buf][chunk][row][unit] own h_{p-1} slice
 
@@ -142,17 +167,17 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     const int jb = blockIdx.x / per_job, rem = blockIdx.x - jb * per_job;
     const int g = rem % a.G, ht = rem / a.G;
     const GruJob& J = a.job[jb];
-    unsigned* ctr = a.counters + jb * a.G + g;
     const int B = a.B;
     const int row_beg = g * a.rows_per_group;
     const int row_end = min(B, row_beg + a.rows_per_group);
     const int ab = a.ablate;
+    const bool one_sc = row_end - row_beg <= 32;               // single super-chunk: lengths stay in registers
 
     // weights -> registers, MFMA B-operand order: B[k][n] = R'[ht*48 + gate*16 + n][k]
     float w[3][KS];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
-        const float* rp = J.R + (size_t)(ht * 48 + gate * 16 + n) * D + wave * 4 * KS;
+        const float* rp = J.R + (size_t)(ht * 48 + gate * 16 + n) * D + wave * WK;
         if (KS % 4 == 0) {
 #pragma unroll
             for (int q = 0; q < KS / 4; ++q) {
@@ -170,9 +195,17 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gate * 16 + gn];
     // which wave / register group holds this workgroup's own 16 columns of h_{p-1}
-    constexpr int WK = 4 * KS;                                  // K range per wave
     const int own_wave = (KS % 4 == 0) ? (ht * 16) / WK : -1;
     const int own_q = (KS % 4 == 0) ? ((ht * 16) % WK) / 16 : 0;
+    // sequence lengths of the rows this thread touches (A rows: lane&15, gate rows: tid>>4)
+    int len_a[2] = {0, 0}, len_g[2] = {0, 0};
+    if (J.reverse) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            len_a[c] = a.lens[min(row_beg + 16 * c + n, B - 1)];
+            len_g[c] = a.lens[min(row_beg + 16 * c + gr, B - 1)];
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
     bool fast = false;
@@ -181,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     int buf = 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_begin; p < a.p_end; ++p) {
+        const bool poll = p > a.p_begin && !(ab & 16);
         for (int rb = row_beg; rb < row_end; rb += 32, buf ^= 1) {
             AVAE_STAMP(7);
             // (1) exchange-independent loads of the gate phase
@@ -192,19 +226,16 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 gpos[c] = 0;
                 gi[c][0] = gi[c][1] = gi[c][2] = 0.f;
                 if (gok[c]) {
-                    gpos[c] = pos_map(p, J.reverse ? a.lens[row] : 0, J.reverse);
+                    const int len = J.reverse ? (one_sc ? len_g[c] : a.lens[row]) : 0;
+                    gpos[c] = pos_map(p, len, J.reverse);
                     if (!(ab & 2)) {
                         const float* gp = J.gi + ((size_t)gpos[c] * B + row) * a.ldg + ht * 48 + gn;
                         gi[c][0] = gp[0]; gi[c][1] = gp[16]; gi[c][2] = gp[32];
                     }
                 }
             }
-            // (2) the group's h_{p-1} must be complete
             AVAE_STAMP(0);
-            if (rb == row_beg && p > a.p_begin && !(ab & 16)) group_wait(ctr, (unsigned)(HT * (p - a.p_begin)), a.err);
-            AVAE_STAMP(1);
-
-            // (3) A operand: every load of both chunks first, then the MFMAs
+            // (2) A operand = h_{p-1} of the group's rows, this wave's K quarter
             float av[2][KS];
             const bool c1 = rb + 16 < row_end;                       // second chunk present (uniform)
 #pragma unroll
@@ -214,24 +245,20 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 unsigned aoff = 0; bool have = !(ab & 1);
                 if (p == 0) { have = have && J.h0 != nullptr; aoff = (unsigned)((size_t)row * D * 4); }
                 else {
-                    int pp = pos_map(p - 1, J.reverse ? a.lens[row] : 0, J.reverse);
-                    aoff = (unsigned)((((size_t)pp * B + row) * a.ldh) * 4);
+                    const int len = J.reverse ? (one_sc ? len_a[c] : a.lens[row]) : 0;
+                    aoff = (unsigned)((((size_t)pos_map(p - 1, len, J.reverse) * B + row) * a.ldh) * 4);
                 }
-                const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
-                if (KS % 4 == 0) {
+                if (!have) {
 #pragma unroll
-                    for (int q = 0; q < KS / 4; ++q) {
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (have) v = load16_sc1(rs, aoff + (wave * WK + 16 * q + 4 * kh) * 4);
-                        av[c][4 * q + 0] = v.x; av[c][4 * q + 1] = v.y; av[c][4 * q + 2] = v.z; av[c][4 * q + 3] = v.w;
-                    }
+                    for (int ks = 0; ks < KS; ++ks) av[c][ks] = 0.f;
+                } else if constexpr (KS % 4 == 0) {
+                    load_frag<KS / 4>(av[c], (p == 0) ? rs_h0 : rs_hs, aoff + (wave * WK + 4 * kh) * 4, poll, a.err);
                 } else {
-                    const float* hsrc = (p == 0) ? J.h0 : J.hs;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-                        av[c][ks] = have ? load4_sc1(hsrc + aoff / 4 + wave * WK + kperm<KS>(ks, kh)) : 0.f;
+                    load_frag_scalar<KS, KS>(av[c], ((p == 0) ? J.h0 : J.hs) + aoff / 4 + wave * WK, 0, kh, poll, a.err);
                 }
             }
+            AVAE_STAMP(1);
+            // (3) MFMAs
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (c == 1 && !c1) break;
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 const float hprev = hps[buf][c][gr][gn];
                 float r, u, nn;
                 if (ab & 8) { r = 0.5f + 0.1f * (gi[c][0] + gh[0]); u = 0.5f + 0.1f * (gi[c][1] + gh[1]); nn = 0.1f * (gi[c][2] + r * gh[2]); }
-                else { r = sigmoidf_(gi[c][0] + gh[0]); u = sigmoidf_(gi[c][1] + gh[1]); nn = tanhf(gi[c][2] + r * gh[2]); }
+                else { r = sigmoidf_(gi[c][0] + gh[0]); u = sigmoidf_(gi[c][1] + gh[1]); nn = tanhf_(gi[c][2] + r * gh[2]); }
                 const float hnew = (1.f - u) * nn + u * hprev;
                 // (6) exchanged store first
                 float* hdst = J.hs + ((size_t)gpos[c] * B + row) * a.ldh + j;
@@ -291,9 +318,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 o_r[c] = r; o_u[c] = u; o_n[c] = nn; o_hn[c] = gh[2]; o_hp[c] = hprev;
             }
             AVAE_STAMP(4);
-            if (rb + 32 >= row_end && p + 1 < a.p_end && !(ab & 16)) group_publish(ctr, fast);
-            AVAE_STAMP(5);
-            // (7) stores nobody in this launch waits for
+            // stores nobody in this launch waits for
             if (!(ab & 4)) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -321,8 +346,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 // step p (descending):  dH_p = dh_out[p] + dH_{p+1} u_{p+1} + dgh_{p+1} R'
 //   dn = dH (1-u)(1-n^2)   du = dH (h_{p-1} - n) u (1-u)   dr = dn hn r (1-r)
 //   dgi = [dr,du,dn]   dgh = [dr,du,dn r]
-// The bias gradients (column sums of dgi / dgh over all rows and steps) are accumulated in
-// registers across the whole launch and leave through one LDS reduction + 96 float atomics.
+// dgh is the exchanged buffer (sentinel-filled by the launcher).  The bias gradients (column sums
+// of dgi / dgh over all rows and steps) are accumulated in registers across the whole launch and
+// leave through one LDS reduction + 96 float atomics.
 template <int KS>
 __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 {
@@ -336,11 +362,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     const int jb = blockIdx.x / per_job, rem = blockIdx.x - jb * per_job;
     const int g = rem % a.G, ht = rem / a.G;
     const GruJob& J = a.job[jb];
-    unsigned* ctr = a.counters + jb * a.G + g;
     const int B = a.B, S = a.S;
     const int row_beg = g * a.rows_per_group;
     const int row_end = min(B, row_beg + a.rows_per_group);
     const int ab = a.ablate;
+    const bool one_sc = row_end - row_beg <= 32;
 
     // B operand: B[k = c'][n] = R'[c'][ht*16 + n]
     float w[NKS];
@@ -350,6 +376,14 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 
     const int gn = tid & 15, gr = tid >> 4;
     const int j = ht * 16 + gn;
+    int len_a[2] = {0, 0}, len_g[2] = {0, 0};
+    if (J.reverse) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            len_a[c] = a.lens[min(row_beg + 16 * c + n, B - 1)];
+            len_g[c] = a.lens[min(row_beg + 16 * c + gr, B - 1)];
+        }
+    }
     const bool want_dh0 = (J.dh0 != nullptr) && a.p_begin == 0;
     const int p_last = want_dh0 ? -1 : a.p_begin;       // p == -1: only dh0 = carry + dgh_0 R'
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
@@ -361,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
         const bool have_next = (p + 1 < S);
+        const bool poll = done > 0 && !(ab & 16);
         for (int rb = row_beg; rb < row_end; rb += 32, buf ^= 1) {
             AVAE_STAMP(7);
             // (1) exchange-independent loads of the gate phase
@@ -371,8 +406,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 gok[c] = row < row_end && p >= 0;
                 rix[c] = 0; s_r[c] = s_u[c] = s_n[c] = s_hn[c] = s_hp[c] = s_do[c] = 0.f;
                 if (gok[c]) {
-                    const int pos = pos_map(p, J.reverse ? a.lens[row] : 0, J.reverse);
-                    rix[c] = pos * B + row;
+                    const int len = J.reverse ? (one_sc ? len_g[c] : a.lens[row]) : 0;
+                    rix[c] = pos_map(p, len, J.reverse) * B + row;
                     if (!(ab & 2)) {
                         const float* sv = J.sv + ((size_t)rix[c] * HT + ht) * 64 + gn;
                         s_r[c] = sv[0]; s_u[c] = sv[16]; s_n[c] = sv[32]; s_hn[c] = sv[48];
@@ -382,33 +417,32 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 }
             }
             AVAE_STAMP(0);
-            if (rb == row_beg && done > 0 && !(ab & 16)) group_wait(ctr, (unsigned)(HT * done), a.err);
-            AVAE_STAMP(1);
-
             const bool c1 = rb + 16 < row_end;
-            // A operand = dgh_{p+1} rows (K = 3D, this wave's quarter).  Two half-chunk register
-            // buffers in flight: the loads of the next half are issued before the MFMAs of the current.
+            // (2)+(3) A operand = dgh_{p+1} rows (K = 3D, this wave's quarter) in pieces: two piece
+            // buffers in flight, the next piece's loads are issued before the MFMAs of the current one;
+            // a piece that still carries sentinels is re-loaded just before it is consumed.
             constexpr int NH = (NKS % 16 == 0) ? 4 : ((NKS % 8 == 0) ? 2 : 1);   // pieces per chunk
             constexpr int HK = NKS / NH;                                          // MFMA steps per piece
             float hv[2][HK];
-            auto load_half = [&](float (&dst)[HK], int c, int hf) {
+            auto piece_off = [&](int c, int hf) -> unsigned {
                 const int row = min(rb + 16 * c + n, B - 1);
-                const int pos1 = pos_map(p + 1, J.reverse ? a.lens[row] : 0, J.reverse);
-                const unsigned aoff = (unsigned)((((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS) * 4);
-                if (NKS % 4 == 0) {
+                const int len = J.reverse ? (one_sc ? len_a[c] : a.lens[row]) : 0;
+                const int pos1 = pos_map(p + 1, len, J.reverse);
+                return (unsigned)((((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS + hf * 4 * HK) * 4);
+            };
+            auto issue = [&](float* dst, int c, int hf) {          // one pass, no check
+                if constexpr (NKS % 4 == 0) load_frag<HK / 4>(dst, rs_dgh, piece_off(c, hf) + 16 * kh, false, a.err);
+                else load_frag_scalar<HK, NKS>(dst, J.dgh + piece_off(c, 0) / 4, hf * HK, kh, false, a.err);
+            };
+            auto has_sentinel = [&](const float* v) -> bool {
+                bool bad = false;
 #pragma unroll
-                    for (int q = 0; q < HK / 4; ++q) {
-                        float4 v = load16_sc1(rs_dgh, aoff + (16 * (q + hf * (HK / 4)) + 4 * kh) * 4);
-                        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int ks = 0; ks < HK; ++ks) dst[ks] = load4_sc1(J.dgh + aoff / 4 + kperm<NKS>(ks + hf * HK, kh));
-                }
+                for (int i = 0; i < HK; ++i) bad |= __float_as_uint(v[i]) == kSentinel;
+                return __any(bad);
             };
             const bool do_mm = have_next && !(ab & 1);
-            const int nstage = (c1 ? 2 : 1) * NH;                     // (chunk, half) stages, uniform
-            if (do_mm) { load_half(hv[0], 0, 0); if (nstage > 1) load_half(hv[1], 1 / NH, 1 % NH); }
+            const int nstage = (c1 ? 2 : 1) * NH;                     // (chunk, piece) stages, uniform
+            if (do_mm) { issue(hv[0], 0, 0); if (nstage > 1) issue(hv[1], 1 / NH, 1 % NH); }
             f32x4 acc[4];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -421,10 +455,14 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                             for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                         if (do_mm) {
+                            if (poll) {
+                                SpinGuard sg;
+                                while (has_sentinel(hv[st & 1]) && !sg.expired(a.err)) issue(hv[st & 1], c, hf);
+                            }
 #pragma unroll
                             for (int ks = 0; ks < HK; ++ks)
                                 acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[st & 1][ks], w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
-                            if (st + 2 < nstage) load_half(hv[st & 1], (st + 2) / NH, (st + 2) % NH);
+                            if (st + 2 < nstage) issue(hv[st & 1], (st + 2) / NH, (st + 2) % NH);
                         }
                         if (hf == NH - 1) {
                             f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -458,8 +496,6 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r;
             }
             AVAE_STAMP(4);
-            if (rb + 32 >= row_end && p > p_last && !(ab & 16)) group_publish(ctr, fast);
-            AVAE_STAMP(5);
             if (p >= 0) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -472,6 +508,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                     }
                 }
             }
+            AVAE_STAMP(6);
         }
     }
     if ((ab & 32) && tid == 0 && a.stamps) {
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 }
 
 // ------------------------------------------------------------------------------ launchers
-constexpr int kGruSyncWords = 64 + 64 + 1536;   // step counters, detection counters, XCD ids (njobs*G*HT)
+constexpr int kGruSyncWords = 64 + 64 + 1536;   // (spare) | detection counters | XCD ids (njobs*G*HT)
 bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 512; }
 
 template <bool FWD>
@@ -526,11 +563,22 @@ static hipError_t check(const GruArgs& a, int* grid)
     return hipSuccess;
 }
 
+// sentinel fill of an exchanged buffer region: rows x width floats at row stride ld
+static hipError_t fill_sentinel(hipStream_t st, float* base, size_t rows, size_t width, size_t ld)
+{
+    if (width == ld) return hipMemsetAsync(base, 0xFF, rows * ld * sizeof(float), st);
+    return hipMemset2DAsync(base, ld * sizeof(float), 0xFF, width * sizeof(float), rows, st);
+}
+
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
-    if (persistent) {
+    if (persistent && a.p_end - a.p_begin > 1) {
         e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
+        // every job's output columns of hs, all positions (jobs of one launch interleave their columns)
+        for (int i = 0; i < a.njobs; ++i) {
+            e = fill_sentinel(st, a.job[i].hs, (size_t)a.S * a.B, a.D, a.ldh); if (e != hipSuccess) return e;
+        }
         return launch<true>(st, a, grid);
     }
     for (int p = a.p_begin; p < a.p_end; ++p) {
@@ -545,24 +593,22 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
         e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
+        for (int i = 0; i < a.njobs; ++i) {
+            e = fill_sentinel(st, a.job[i].dgh, (size_t)a.S * a.B, 3 * (size_t)a.D, a.ldg); if (e != hipSuccess) return e;
+        }
         return launch<false>(st, a, grid);
     }
-    // one launch per step (descending); the dh0 tail (p = -1) rides with p = 0 only in the
-    // persistent form, so split it: steps S-1..1, then [0,1) which also emits dh0 after a sync
+    // one launch per step (descending); the dh0 tail (p = -1) is its own launch
     for (int p = a.p_end - 1; p >= a.p_begin; --p) {
         GruArgs b = a; b.p_begin = p; b.p_end = p + 1;
+        for (int i = 0; i < b.njobs; ++i) b.job[i].dh0 = nullptr;
+        e = launch<false>(st, b, grid); if (e != hipSuccess) return e;
         if (p == 0) {
-            // run step 0 without the tail, then the tail alone
-            GruArgs c = b; for (int i = 0; i < c.njobs; ++i) c.job[i].dh0 = nullptr;
-            e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
-            e = launch<false>(st, c, grid); if (e != hipSuccess) return e;
             bool any = false; for (int i = 0; i < a.njobs; ++i) any |= a.job[i].dh0 != nullptr;
             if (any) {
-                GruArgs d = b; d.p_begin = 0; d.p_end = 0;   // loop runs p = -1 only
+                GruArgs d = a; d.p_begin = 0; d.p_end = 0;   // loop runs p = -1 only
                 e = launch<false>(st, d, grid); if (e != hipSuccess) return e;
             }
-        } else {
-            e = launch<false>(st, b, grid); if (e != hipSuccess) return e;
         }
     }
     return hipSuccess;

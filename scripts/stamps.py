@@ -7,7 +7,7 @@ from argsim_amd.model import VAE
 m = VAE('train', seed=0, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 m.step = 20000
 ids = torch.as_tensor(synth.batch(256, 64, 8192, seed=0)).cuda()
-names = ['prefetch', 'wait', 'Aload+mfma', 'barrier', 'gates', 'publish', 'tail', 'loop']
+names = ['prefetch', 'Aload+poll', 'mfma', 'barrier', 'gates', 'unused', 'tail', 'loop']
 for extra in (0, 16):
     for slow in (0, 1):
         m.set_option('gru_force_slow', slow)
