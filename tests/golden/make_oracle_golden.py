@@ -1,0 +1,30 @@
+"""writes tests/golden/oracle_<case>.npz: inputs and reduced outputs of the float64 oracle for the
+parity cases of tests/helpers.py (losses, z, mu, pred, per-variable gradient norms).
+
+    python tests/golden/make_oracle_golden.py
+
+The reference itself cannot be run (TensorFlow absent, CudnnGRU GPU-only): these vectors pin the
+ORACLE against drift, they are not reference outputs ("parity unpinned", oracle/__init__.py)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from helpers import CASES, make_case  # noqa: E402
+from oracle import vae_numpy as vn  # noqa: E402
+from oracle import vae_torch as vt  # noqa: E402
+
+for name in CASES:
+    cfg, P, ids, keep, eps = make_case(name)
+    o = vn.forward(P, cfg, ids, ids, 'train', 20000, keep, eps)
+    out = dict(ids=ids, keep=keep, eps=eps, loss=o['loss'], loss_gen=o['loss_gen'], loss_kld=o['loss_kld'],
+               z=o['z'], mu=o['mu'], lv=o['lv'], pred=o['pred'], loss_gen_samp=o['loss_gen_samp'])
+    if name != 'full2':
+        _, grads = vt.loss_and_grads(P, cfg, ids, ids, 20000, keep, eps)
+        for k, g in grads.items():
+            out['gnorm/' + k] = np.linalg.norm(g)
+    np.savez_compressed(os.path.join(HERE, 'oracle_%s.npz' % name), **out)
+    print(name, float(o['loss']))

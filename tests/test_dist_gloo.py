@@ -1,0 +1,120 @@
+"""data-parallel path on CPU: two gloo ranks, each with an oracle-backed stand-in for the device model,
+shard a ragged global batch, scale by the GLOBAL token / row counts, all-reduce bucket by bucket through
+argsim_amd.dist, and must reproduce the single-process gradient and one TF-Adam update."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleModel:
+    """same surface as argsim_amd.model.VAE for DataParallel (grads, buckets, hook, forward_backward, adam_step)"""
+
+    def __init__(self, cfg, P):
+        from oracle import vae_torch as vt
+        self.vt, self.cfg = vt, cfg
+        self.names = list(P)
+        self.sizes = [int(np.prod(P[k].shape)) for k in self.names]
+        self.offs = np.concatenate([[0], np.cumsum(self.sizes)])
+        n = int(self.offs[-1])
+        self.params = torch.zeros(n, dtype=torch.float64)
+        for k, o in zip(self.names, self.offs):
+            self.params[o:o + P[k].size] = torch.tensor(P[k].ravel())
+        self.grads = torch.zeros(n, dtype=torch.float64)
+        self.m = torch.zeros(n, dtype=torch.float64)
+        self.v = torch.zeros(n, dtype=torch.float64)
+        self.step = 20000
+        self.hook = None
+        self.shapes = {k: P[k].shape for k in self.names}
+
+    def buckets(self):
+        # three uneven buckets covering the flat buffer
+        n = len(self.grads)
+        cuts = [0, n // 5, n // 2, n]
+        return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)]
+
+    def set_grad_hook(self, fn):
+        self.hook = fn
+
+    def unflat(self, flat):
+        return {k: flat[o:o + s].reshape(self.shapes[k]).numpy() for k, o, s in zip(self.names, self.offs, self.sizes)}
+
+    def forward_backward(self, src, tgt, seed=None, keep_mask=None, eps=None, n_tok_global=0.0, b_global=0.0):
+        vt, cfg = self.vt, self.cfg
+        P = vt.to_torch(self.unflat(self.params))
+        o = vt.forward(P, cfg, src, tgt, 'train', self.step, keep_mask, eps)
+        n_loc = float(o['loss_gen_samp'].numel())
+        b_loc = float(len(src))
+        R = cfg['dim_rep']
+        anneal = float(np.tanh(cfg['accelerate'] * self.step))
+        # global-mean ELBO restricted to this shard: sums scaled by the GLOBAL denominators
+        loss = o['loss_gen_samp'].sum() / (n_tok_global or n_loc) + anneal * o['loss_kld_samp'].sum() / ((b_global or b_loc) * R)
+        loss.backward()
+        g = torch.cat([(P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])).reshape(-1) for k in self.names])
+        self.grads.copy_(g)
+        if self.hook:
+            for i, (off, cnt) in enumerate(self.buckets()):
+                self.hook(i, off, cnt)
+
+    def adam_step(self):
+        from oracle import vae_numpy as vn
+        lr = vn.schedule(self.step, self.cfg['accelerate'], self.cfg['learn_rate'])[2]
+        p, m, v = vn.adam_tf({'x': self.params.numpy()}, {'x': self.grads.numpy()}, {'x': self.m.numpy()}, {'x': self.v.numpy()}, self.step, lr)
+        self.params, self.m, self.v = torch.tensor(p['x']), torch.tensor(m['x']), torch.tensor(v['x'])
+        self.step += 1
+
+
+def _case():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import make_case
+    return make_case('mid')
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from argsim_amd.dist import DataParallel, global_token_count, shard_rows
+    cfg, P, ids, keep, eps = _case()
+    model = OracleModel(cfg, P)
+    dp = DataParallel(model, overlap=(rank >= 0))
+    lo, hi = shard_rows(len(ids), rank, world)
+    n_loc = int((ids[lo:hi] != cfg['eos']).sum() + (hi - lo))
+    n_glob = global_token_count(n_loc)
+    # NB: each shard is trimmed to ITS longest row by the model; keep_mask rows beyond it are unused
+    smax = int((ids[lo:hi] != cfg['eos']).sum(1).max())
+    dp.train_step(ids[lo:hi], ids[lo:hi], n_glob, float(len(ids)), keep_mask=keep[:smax, lo:hi], eps=eps[lo:hi])
+    if rank == 0:
+        torch.save({'grads': model.grads, 'params': model.params, 'n_glob': n_glob}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    out = str(tmp_path / 'r0.pt')
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    cfg, P, ids, keep, eps = _case()
+    ref = OracleModel(cfg, P)
+    ref.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    assert got['n_glob'] == float((ids != cfg['eos']).sum() + len(ids))
+    d = (got['grads'] - ref.grads).norm() / ref.grads.norm()
+    assert float(d) < 1e-12, float(d)
+    ref.adam_step()
+    assert float((got['params'] - ref.params).abs().max()) < 1e-12
+
+
+def test_shard_rows_and_reducer_bookkeeping():
+    from argsim_amd.dist import shard_rows
+    assert [shard_rows(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
+    with pytest.raises(AssertionError):
+        shard_rows(10, 0, 4)

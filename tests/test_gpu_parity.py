@@ -228,3 +228,25 @@ def test_bench_scale_persistent_equals_stepwise():
     import torch
     d = (g1 - g0).norm() / g0.norm()
     assert float(d) < 1e-5, float(d)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_against_committed_golden(name):
+    """the HIP path against the committed fixtures (tests/golden/oracle_*.npz), not only the live oracle"""
+    import os
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'oracle_%s.npz' % name)
+    with np.load(path, allow_pickle=False) as f:
+        gold = {k: f[k] for k in f.files}
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P)
+    m.step = 20000
+    z = m.encode(gold['ids'])
+    assert np.abs(z - gold['mu']).max() <= 2e-5
+    m.forward_backward(gold['ids'], gold['ids'], keep_mask=gold['keep'], eps=gold['eps'])
+    lg, lk, lo = m.losses()
+    assert abs(lo - float(gold['loss'])) <= 2e-5 * abs(float(gold['loss']))
+    if name != 'full2':
+        g = m.get_grads()
+        for k, v in g.items():
+            want = float(gold['gnorm/' + k])
+            assert abs(np.linalg.norm(v.astype(np.float64)) - want) <= 2e-4 * max(want, 1e-12), k

@@ -1,0 +1,168 @@
+"""CPU tests of the host side: batching helpers against goldens captured from the reference, the
+tokeniser wrappers, the batch generator / prefetch pipe, checkpoint name mapping."""
+import json
+import os
+from itertools import islice
+
+import numpy as np
+import pytest
+
+from argsim_amd import util_np, util_sp
+from argsim_amd.util import Record, comp
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_util_np_against_reference_goldens():
+    g = json.load(open(os.path.join(GOLD, 'util_np_golden.json')))
+    for c in g['vpack']:
+        assert util_np.vpack(c['arrays'], tuple(c['shape']), c['fill'], np.int32).tolist() == c['result']
+    for c in g['partition']:
+        assert [list(p) for p in util_np.partition(c['n'], c['m'], c['discard'])] == c['result']
+    for c in g['sample']:
+        assert list(islice(util_np.sample(c['n'], c['seed']), len(c['result']))) == c['result']
+
+
+def test_survey_known_answers():
+    # SURVEY.md section 8c
+    assert list(islice(util_np.sample(5, 0), 12)) == [2, 0, 1, 3, 4, 1, 2, 0, 3, 4, 0, 1]
+    assert util_np.vpack([[1, 2, 3], [4]], (2, 4), 1, np.int32).tolist() == [[1, 2, 3, 1], [4, 1, 1, 1]]
+    assert list(util_np.partition(10, 4)) == [(0, 4), (4, 8), (8, 10)]
+
+
+def test_vpack_edge_cases():
+    assert util_np.vpack([], (0, 3), 1, np.int32).shape == (0, 3)
+    assert util_np.vpack([[], []], (2, 2), 7, np.int32).tolist() == [[7, 7], [7, 7]]
+    with pytest.raises(ValueError):
+        util_np.vpack([[1, 2, 3]], (1, 2), 0, np.int32)       # row longer than the shape: reference raises too
+
+
+def test_sample_does_not_touch_global_rng():
+    np.random.seed(123)
+    a = np.random.rand()
+    np.random.seed(123)
+    list(islice(util_np.sample(9, 4), 30))
+    assert np.random.rand() == a
+
+
+def test_record_and_comp():
+    r = Record({'a': 1}, b=2)
+    assert r.a == 1 and r['b'] == 2 and dict(**r) == {'a': 1, 'b': 2} and len(r) == 2
+    assert comp(lambda x: x + 1, lambda x: 2 * x, lambda x: x - 3)(5) == 5
+
+
+def test_sentence_splitter():
+    s = util_sp.sent_split('Dr. Smith went home. He slept! "Why?" she asked. The U.S. is big (really.) Yes')
+    assert s[0] == 'Dr. Smith went home.' and s[1] == 'He slept!' and s[-1] == 'Yes'
+    assert util_sp.sent_split('') == [] and util_sp.sent_split('no boundary') == ['no boundary']
+
+
+@pytest.fixture(scope='module')
+def vocab(tmp_path_factory):
+    d = tmp_path_factory.mktemp('spm')
+    rng = np.random.default_rng(0)
+    words = ['argument', 'stance', 'abortion', 'rights', 'gun', 'control', 'people', 'think', 'because', 'evidence',
+             'the', 'a', 'of', 'and', 'is', 'not', 'that', 'should', 'we', 'they', 'law', 'state', 'debate', 'claim']
+    lines = []
+    for _ in range(400):
+        n = int(rng.integers(3, 9))
+        sents = [' '.join(rng.choice(words, int(rng.integers(4, 12)))) + '.' for _ in range(n)]
+        lines.append(' '.join(sents))
+    path = os.path.join(d, 'train.txt')
+    with open(path, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    v = util_sp.spm(os.path.join(d, 'vocab'), path, size=48)
+    return v, path, lines
+
+
+def test_spm_ids_and_roundtrip(vocab):
+    v, path, lines = vocab
+    assert (v.unk_id(), v.eos_id(), v.bos_id()) == (0, 1, 2)          # util_sp.py:17
+    ids = util_sp.encode(v, lines[:5])
+    assert ids.dtype == np.int32 and ids.shape[0] == 5
+    assert (ids[:, -1] == v.eos_id()).any() or ids.shape[1] == max(len(v.encode_as_ids(s)) for s in lines[:5])
+    back = list(util_sp.decode(v, ids))
+    assert back == lines[:5]
+
+
+def test_encode_capped_ladder(vocab):
+    v, path, lines = vocab
+    text = lines[0]
+    full = v.encode_as_ids(text)
+    assert util_sp.encode_capped(v, text, cap=len(full)) == full
+    cap = len(full) // 2
+    ids = util_sp.encode_capped(v, text, cap=cap)
+    assert 0 < len(ids) <= cap
+    # what fits is a whole number of leading sentences, as in the reference's fall-back
+    sents = util_sp.sent_split(text)
+    assert any(ids == v.encode_as_ids(' '.join(sents[:n])) for n in range(1, len(sents) + 1))
+    # even the first sentence does not fit: hard truncation
+    assert len(util_sp.encode_capped(v, text, cap=2)) == 2
+    s = util_sp.encode_capped_sample(v, text, cap=cap)
+    assert len(s) <= cap
+    a, b = util_sp.encode_capped_sample_pair(v, text, cap=cap)
+    assert len(a) <= cap and len(b) <= cap
+
+
+def test_batch_generator_and_pipe(vocab):
+    from argsim_amd.train import batch, pipe
+    v, path, lines = vocab
+    gen = batch(8, path, v, seed=0, kudo=False, max_len=16)
+    src, tgt = next(gen)
+    assert src is tgt and src.shape[0] == 8 and src.shape[1] <= 16 and src.dtype == np.int32
+    # order follows util_np.sample; rows are eos padded
+    order = list(islice(util_np.sample(len(lines), 0), 8))
+    for row, i in zip(src, order):
+        want = util_sp.encode_capped(v, lines[i], cap=16)
+        assert row[:len(want)].tolist() == want and (row[len(want):] == v.eos_id()).all()
+    gen2 = batch(4, path, v, seed=0, kudo=True, max_len=16)
+    s2, t2 = next(gen2)
+    assert s2.shape[0] == t2.shape[0] == 4
+    got = list(islice(pipe(iter(range(10)), prefetch=3), 10))
+    assert got == list(range(10))
+
+
+def test_checkpoint_tf_name_roundtrip():
+    from argsim_amd import ckpt
+    from oracle import vae_numpy as vn
+    cfg = vn.make_cfg(dim_tgt=32, dim_emb=16, dim_rep=8, rnn_layers=2)
+    P = vn.init_params(cfg, 0, bias_scale=0.1)
+    tf = ckpt.to_tf_names(P)
+    assert 'embed/embedding' in tf and 'latent/mu/kernel' in tf
+    k = 'decode/rnn/cudnn_gru/rnn/multi_rnn_cell/cell_1/cudnn_compatible_gru_cell/gates/kernel'
+    assert tf[k].shape == (16 + 16, 32)
+    e = 'encode/rnn2/bwd/cudnn_gru/rnn/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/candidate/input_projection/kernel'
+    assert tf[e].shape == (32, 16)
+    back = ckpt.from_tf_names(tf, list(P))
+    for name in P:
+        if name.endswith('/bW') or name.endswith('/bR'):
+            continue
+        assert np.array_equal(back[name], P[name]), name
+    # r/u biases come back summed into bW (same function), candidate biases exactly
+    D = 16
+    for base in ('decode/rnn/l1/', 'encode/rnn1/fwd/'):
+        assert np.allclose(back[base + 'bW'][:2 * D] + back[base + 'bR'][:2 * D], P[base + 'bW'][:2 * D] + P[base + 'bR'][:2 * D])
+        assert np.array_equal(back[base + 'bW'][2 * D:], P[base + 'bW'][2 * D:])
+        assert np.array_equal(back[base + 'bR'][2 * D:], P[base + 'bR'][2 * D:])
+    # equivalence of the function: the oracle gives the same z with the converted parameters
+    ids = np.array([[3, 4, 5, 1], [6, 7, 1, 1]], np.int32)
+    z0 = vn.forward(P, cfg, ids, ids, 'valid')['z']
+    z1 = vn.forward({k: back[k] for k in P}, cfg, ids, ids, 'valid')['z']
+    assert np.abs(z0 - z1).max() < 1e-12
+
+
+def test_train_cli_flags_match_reference():
+    from argsim_amd.train import parse_args
+    A = parse_args(['--rounds', '2', '--sample', '--trial', 'x'])
+    assert (A.trial, A.config, A.ckpt, A.gpu, A.seed, A.rounds, A.prefetch, A.sample, A.profile) == \
+        ('x', 'config.json', None, '0', 0, 2, 16, True, False)
+
+
+def test_synthetic_batches():
+    from argsim_amd import synth
+    a = synth.batch(16, 12, 8192, seed=0)
+    assert a.shape == (16, 12) and a.dtype == np.int32 and a.min() >= 3 and a.max() < 8192
+    r = synth.batch(64, 64, 8192, ragged=True, seed=0)
+    lens = (r != 1).sum(1)
+    assert lens.min() >= 2 and lens.max() <= 64 and (lens < 64).any()
+    assert np.array_equal(a, synth.batch(16, 12, 8192, seed=0))
