@@ -16,23 +16,20 @@ namespace avae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 constexpr int LDK = BK + 4;     // k-contiguous tile row stride (floats): conflict-free b128 reads
-constexpr int TILE_FLOATS = BM * LDK;   // >= BK*BM
 
-__device__ __forceinline__ int kmap(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
-
-// stage one operand tile (128 x 32) global -> 4 float4 registers per thread
-template <bool XC>   // XC: x(m or n)-contiguous storage [k][x];  else k-contiguous [x][k]
-__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ P, int ld,
+// stage one operand tile (ROWS x 32) global -> ROWS/32 float4 registers per thread
+template <bool XC, int ROWS>   // XC: x(m or n)-contiguous storage [k][x];  else k-contiguous [x][k]
+__device__ __forceinline__ void load_tile(float4 (&r)[ROWS / 32], const float* __restrict__ P, int ld,
                                           int x0, int X, int k0, int K1, int tid)
 {
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < ROWS / 32; ++rep) {
         int f = tid + 256 * rep;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (XC) {
-            int k = k0 + (f >> 5), x = x0 + ((f & 31) << 2);
+            int k = k0 + f / (ROWS / 4), x = x0 + ((f % (ROWS / 4)) << 2);
             if (k < K1 && x < X) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);
         } else {
             int x = x0 + (f >> 3), k = k0 + ((f & 7) << 2);
@@ -42,27 +39,31 @@ __device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restric
     }
 }
 
-template <bool XC>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid)
+template <bool XC, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[ROWS / 32], int tid)
 {
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < ROWS / 32; ++rep) {
         int f = tid + 256 * rep;
-        if (XC) *reinterpret_cast<float4*>(s + (f >> 5) * BM + ((f & 31) << 2)) = r[rep];
+        if (XC) *reinterpret_cast<float4*>(s + (f / (ROWS / 4)) * ROWS + ((f % (ROWS / 4)) << 2)) = r[rep];
         else    *reinterpret_cast<float4*>(s + (f >> 3) * LDK + ((f & 7) << 2)) = r[rep];
     }
 }
 
-template <bool A_MC, bool B_NC>
+// WM x WN waves (WM*WN = 4), each TM x TN MFMA tiles of 32x32: block tile BM = 32 WM TM, BN = 32 WN TN.
+// <2,2,2,2> = 128x128 is the workhorse; <1,4,1,1> = 32x128 serves thin row panels (M <= 512 and the
+// remainder rows of a tile count just above a multiple of 256) deterministically, without split-K.
+template <bool A_MC, bool B_NC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
     float* As = smem;
-    float* Bs = smem + TILE_FLOATS;
+    float* Bs = smem + BM * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     int M = g.M, K = g.K;
     if (g.dyn_kind == 1) M = min(M, *g.dyn);
@@ -91,52 +92,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         if (kb >= ke) return;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[4], rb[4];
-    load_tile<A_MC>(ra, g.A, g.lda, m0, M, kb, ke, tid);
-    load_tile<B_NC>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    float4 ra[BM / 32], rb[BN / 32];
+    load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, kb, ke, tid);
+    load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
 
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        store_tile<A_MC>(As, ra, tid);
-        store_tile<B_NC>(Bs, rb, tid);
+        store_tile<A_MC, BM>(As, ra, tid);
+        store_tile<B_NC, BN>(Bs, rb, tid);
         __syncthreads();
         if (k0 + BK < ke) {
-            load_tile<A_MC>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
-            load_tile<B_NC>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
+            load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
+            load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float a[2][4], b[2][4];
+            float a[TM][4], b[TN][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TM; ++t) {
                 if (A_MC) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[t][e] = As[(8 * q + 4 * h + e) * BM + 64 * wm + 32 * t + l31];
+                    for (int e = 0; e < 4; ++e) a[t][e] = As[(8 * q + 4 * h + e) * BM + 32 * (wm * TM + t) + l31];
                 } else {
-                    float4 v = *reinterpret_cast<const float4*>(As + (64 * wm + 32 * t + l31) * LDK + 8 * q + 4 * h);
+                    float4 v = *reinterpret_cast<const float4*>(As + (32 * (wm * TM + t) + l31) * LDK + 8 * q + 4 * h);
                     a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
                 }
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
                 if (B_NC) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[t][e] = Bs[(8 * q + 4 * h + e) * BN + 64 * wn + 32 * t + l31];
+                    for (int e = 0; e < 4; ++e) b[t][e] = Bs[(8 * q + 4 * h + e) * BN + 32 * (wn * TN + t) + l31];
                 } else {
-                    float4 v = *reinterpret_cast<const float4*>(Bs + (64 * wn + 32 * t + l31) * LDK + 8 * q + 4 * h);
+                    float4 v = *reinterpret_cast<const float4*>(Bs + (32 * (wn * TN + t) + l31) * LDK + 8 * q + 4 * h);
                     b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
                 }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -146,15 +150,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     const bool atomic = g.split_k > 1;
     const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int col = n0 + 64 * wn + 32 * j + l31;
+    for (int j = 0; j < TN; ++j) {
+        int col = n0 + 32 * (wn * TN + j) + l31;
         if (col >= g.N) continue;
         float bv = add_bias ? g.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                int row = m0 + 32 * (wm * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= M) continue;
                 float v = g.alpha * acc[i][j][r] + bv;
                 float* c = g.C + (size_t)row * g.ldc + col;
@@ -164,6 +168,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             }
         }
     }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
+{
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
+    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
+    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
+    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
+    else                     hipLaunchKernelGGL((gemm_f32_kernel<true, false, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
 }
 
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
@@ -176,12 +192,8 @@ hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     if (a_mc && (g.M & 3)) return hipErrorInvalidValue;
     if (!b_nc && (g.K & 3)) return hipErrorInvalidValue;
     if (b_nc && (g.N & 3)) return hipErrorInvalidValue;
-    int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
-    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
-    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
-    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
-    else                     hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+    if (g.thin) launch_variant<1, 4, 1, 1>(st, a_mc, b_nc, g);
+    else        launch_variant<2, 2, 2, 2>(st, a_mc, b_nc, g);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ struct GemmArgs {
     int accumulate;      // C += ...
     int split_k;
     const int* dyn; int dyn_kind;
+    int thin;            // 1: 32x128 block tiles (thin row panels) instead of 128x128
 };
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 

@@ -8,6 +8,7 @@
 #include "../../include/argsim_vae.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -184,24 +185,64 @@ int get_ws(avae_ctx* h, Ws& w, int B, int Ss, int St, bool train)
 }
 
 // -------------------------------------------------------------------------------- helpers
-int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
-         int M, int N, int K, float alpha = 1.f, const float* bias = nullptr, int accumulate = 0, int split_k = 1,
-         const int* dyn = nullptr, int dyn_kind = 0)
+int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
+             int M, int N, int K, float alpha, const float* bias, int accumulate, int split_k, const int* dyn, int dyn_kind,
+             int thin = 0)
 {
-    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind};
+    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin};
     Timed t(h, 0, 2.0 * M * N * K);
     AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
     return 0;
 }
-// K-split so that a weight-gradient GEMM (few output tiles, very long K) fills the 256 CUs
+
+// C = alpha * op(A) op(B) (+bias) with launch shaping for the 256-CU chip (k-contiguous A only):
+//  * thin outputs (M <= 512): 32x128 block tiles so that the few rows still spread over many CUs;
+//    where float atomics are acceptable (backward) a long K is split over ~768 workgroups instead;
+//  * a tile count just above a multiple of 256 (M = 65*256 rows -> 130 row tiles): the rows that make
+//    whole rounds of 256 tiles run as one launch and the thin remainder as 32x128 tiles, instead of a
+//    few CUs carrying an extra full tile while the rest idle.
+// Both forward forms are deterministic (no atomics): z and the per-token losses stay bit-reproducible.
+int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
+         int M, int N, int K, float alpha = 1.f, const float* bias = nullptr, int accumulate = 0, int split_k = 0,
+         const int* dyn = nullptr, int dyn_kind = 0, bool allow_atomic = false)
+{
+    const int mt = (M + 127) / 128, nt = (N + 127) / 128, tiles = mt * nt;
+    if (split_k != 0 || a_mc || dyn_kind == 2)
+        return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, split_k ? split_k : 1, dyn, dyn_kind);
+    if (tiles <= 96) {
+        if (allow_atomic && !accumulate && ldc == N && K >= 512) {
+            int s = std::min(768 / tiles, K / 128);
+            if (s >= 2) {
+                AV_CHECK(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, h->stream));
+                return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, 0, s, dyn, dyn_kind);
+            }
+        }
+        if (M <= 512)
+            return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 1);
+    }
+    if (tiles > 256 && tiles % 256 != 0) {
+        int main_mt = mt;
+        while (main_mt > 0 && (main_mt * nt) % 256 != 0) --main_mt;
+        const int tail_tiles = (mt - main_mt) * nt;
+        const double frac = (double)tiles / 256.0;
+        if (main_mt > 0 && tail_tiles < 200 && (std::ceil(frac) - frac) >= 0.3) {
+            const int main_rows = main_mt * 128, tail_rows = M - main_rows;
+            AV_TRY(gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, main_rows, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind));
+            // rows beyond the device-side row count hold unread garbage either way: the tail keeps the static bound
+            return gemm_raw(h, a_mc, b_nc, A + (size_t)main_rows * lda, lda, Bm, ldb, C + (size_t)main_rows * ldc, ldc,
+                            tail_rows, N, K, alpha, bias, accumulate, 1, nullptr, 0, 1);
+        }
+    }
+    return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind);
+}
+// K-split so that a weight-gradient GEMM (few output tiles, very long K) fills the chip: aim at 768
+// co-resident workgroups (3 per CU), every slice at least 4 K-tiles deep
 int grad_split(int M, int N, int K)
 {
     int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles >= 192) return 1;
-    int s = (512 + tiles - 1) / tiles;
-    int kmax = K / 256; if (kmax < 1) kmax = 1;
+    int s = 768 / tiles;
+    int kmax = K / 128; if (kmax < 1) kmax = 1;
     if (s > kmax) s = kmax;
-    if (s > 64) s = 64;
     return s < 1 ? 1 : s;
 }
 // dW (M x N) += A^T B over K rows; A [k][m] lda, B [k][n] ldb.  grads are zero-filled beforehand.
@@ -209,7 +250,7 @@ int gemm_tn_grad(avae_ctx* h, const float* A, int lda, const float* Bm, int ldb,
                  float alpha = 1.f, const int* dynk = nullptr)
 {
     int s = grad_split(M, N, K);
-    return gemm(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0);
+    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0);
 }
 
 void gru_geometry(int D, int njobs, int B, int* G, int* rpg)
@@ -322,8 +363,8 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.lead, w.emb_tgt, rt, D, V));
     AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train));
     AV_CHECK(rows_gather(h->stream, w.hc, w.d_hd[L - 1], w.cidx, w.ntok, rt, D));
-    AV_TRY(gemm(h, false, true, w.hc, D, h->P + h->oKout, D, w.ho, D, rt, D, D, 1.f, h->P + h->oBout, 0, 1, w.ntok, 1));
-    AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 1, w.ntok, 1));
+    AV_TRY(gemm(h, false, true, w.hc, D, h->P + h->oKout, D, w.ho, D, rt, D, D, 1.f, h->P + h->oBout, 0, 0, w.ntok, 1));
+    AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 0, w.ntok, 1));
     CeArgs c{};
     c.logits = w.logits; c.gold = w.gold; c.cidx = w.cidx; c.n_dev = w.ntok; c.n_max = rt; c.V = V;
     c.write_grad = train ? 1 : 0; c.inv_n = inv_n;
@@ -351,12 +392,12 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_CHECK(hipMemsetAsync(G, 0, sizeof(float) * h->numel, st));
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
-    AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 1, w.ntok, 1));
+    AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1));
     AV_TRY(gemm(h, true, true, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, nullptr, 0, 1, w.ntok, 2));
     // out affine
     AV_TRY(gemm_tn_grad(h, w.hc, D, w.dho, D, G + h->oKout, D, D, D, rt, 1.f, w.ntok));
     AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));
-    AV_TRY(gemm(h, false, false, w.dho, D, P + h->oKout, D, w.dhc, D, rt, D, D, 1.f, nullptr, 0, 1, w.ntok, 1));
+    AV_TRY(gemm(h, false, false, w.dho, D, P + h->oKout, D, w.dhc, D, rt, D, D, 1.f, nullptr, 0, 0, w.ntok, 1));
     fire_hook(h, 0);
     AV_CHECK(rows_expand(st, w.dhd[0], w.dhc, w.rank, rt, D));
 
@@ -674,7 +715,8 @@ int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const flo
                     int M, int N, int K, int lda, int ldb, int ldc, float alpha, int accumulate, int split_k)
 {
     if (!h) return 1;
-    return gemm(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k);
+    // split_k == -1 selects the thin (32x128 tile) variant
+    return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : split_k, nullptr, 0, split_k < 0 ? 1 : 0);
 }
 int avae_bucket_count(avae_handle h) { return h ? (int)h->buckets.size() : 0; }
 int avae_bucket_info(avae_handle h, int i, int64_t* offset, int64_t* count)
