@@ -570,15 +570,29 @@ static hipError_t fill_sentinel(hipStream_t st, float* base, size_t rows, size_t
     return hipMemset2DAsync(base, ld * sizeof(float), 0xFF, width * sizeof(float), rows, st);
 }
 
+// sentinel-fill the exchanged buffer of every job; jobs that tile whole rows side by side (the two
+// encoder directions) are covered by ONE linear fill instead of strided 2-D fills
+static hipError_t fill_exchange(hipStream_t st, const GruArgs& a, bool fwd)
+{
+    const size_t rows = (size_t)a.S * a.B, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
+    float* base0 = fwd ? a.job[0].hs : a.job[0].dgh;
+    bool side_by_side = (size_t)a.njobs * width == ld;
+    for (int i = 0; i < a.njobs && side_by_side; ++i)
+        side_by_side = (fwd ? a.job[i].hs : a.job[i].dgh) == base0 + i * width;
+    if (side_by_side) return fill_sentinel(st, base0, rows, ld, ld);
+    for (int i = 0; i < a.njobs; ++i) {
+        hipError_t e = fill_sentinel(st, fwd ? a.job[i].hs : a.job[i].dgh, rows, width, ld);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
         e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
-        // every job's output columns of hs, all positions (jobs of one launch interleave their columns)
-        for (int i = 0; i < a.njobs; ++i) {
-            e = fill_sentinel(st, a.job[i].hs, (size_t)a.S * a.B, a.D, a.ldh); if (e != hipSuccess) return e;
-        }
+        e = fill_exchange(st, a, true); if (e != hipSuccess) return e;
         return launch<true>(st, a, grid);
     }
     for (int p = a.p_begin; p < a.p_end; ++p) {
@@ -593,9 +607,7 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
         e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
-        for (int i = 0; i < a.njobs; ++i) {
-            e = fill_sentinel(st, a.job[i].dgh, (size_t)a.S * a.B, 3 * (size_t)a.D, a.ldg); if (e != hipSuccess) return e;
-        }
+        e = fill_exchange(st, a, false); if (e != hipSuccess) return e;
         return launch<false>(st, a, grid);
     }
     // one launch per step (descending); the dh0 tail (p = -1) is its own launch

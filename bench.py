@@ -154,8 +154,17 @@ def main():
             total_ms = 1e3 * dt
             name, (ms, n, fl) = max(tm.items(), key=lambda kv: kv[1][0])
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic = None
+            try:   # HBM bytes per launch of this kernel class from the separate rocprofv3 --pmc passes
+                   # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; scripts/summarize_profile.py)
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
+                if name == 'gemm':
+                    traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                               "frac": ach / PEAK_F32_MFMA, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                               "flops_per_launch": fl / max(n, 1),
                                "launches_per_step": n / A.steps, "avg_launch_ms": ms / max(n, 1),
                                "share_of_step": ms / total_ms,
                                "classes": {k: {"ms_per_step": v[0] / A.steps, "launches_per_step": v[1] / A.steps,
