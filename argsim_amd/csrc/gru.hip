@@ -9,7 +9,7 @@
 // Decomposition.  One workgroup (4 waves) owns 16 hidden units (x3 gates) of one job
 // (= one layer-direction) for one batch group.  Its 48xD slice of R lives in REGISTERS for
 // the whole launch, already in v_mfma_f32_16x16x4_f32 B-operand order (3*D/16 VGPRs per lane);
-// the four waves split K, partial sums meet in LDS, then 256 threads do the gate math.
+// (rows in "G16" order c' = (unit/16)*48 + (unit%16)*3 + gate, see kernels.h); the four waves split K, partial sums meet in LDS, then 256 threads do the gate math.
 // Per step a workgroup reads only its group's h_{t-1} rows (A operand) and writes its
 // 16-column slice of h_t.
 //
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     float w[3][KS];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
-        const float* rp = J.R + (size_t)(ht * 48 + gate * 16 + n) * D + wave * WK;
+        const float* rp = J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wave * WK;
         if (KS % 4 == 0) {
 #pragma unroll
             for (int q = 0; q < KS / 4; ++q) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     const int j = ht * 16 + gn;
     float bR[3];
 #pragma unroll
-    for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gate * 16 + gn];
+    for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
     // which wave / register group holds this workgroup's own 16 columns of h_{p-1}
     const int own_wave = (KS % 4 == 0) ? (ht * 16) / WK : -1;
     const int own_q = (KS % 4 == 0) ? ((ht * 16) % WK) / 16 : 0;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                     const int len = J.reverse ? (one_sc ? len_g[c] : a.lens[row]) : 0;
                     gpos[c] = pos_map(p, len, J.reverse);
                     if (!(ab & 2)) {
-                        const float* gp = J.gi + ((size_t)gpos[c] * B + row) * a.ldg + ht * 48 + gn;
-                        gi[c][0] = gp[0]; gi[c][1] = gp[16]; gi[c][2] = gp[32];
+                        const float* gp = J.gi + ((size_t)gpos[c] * B + row) * a.ldg + ht * 48 + gn * 3;
+                        gi[c][0] = gp[0]; gi[c][1] = gp[1]; gi[c][2] = gp[2];
                     }
                 }
             }
@@ -325,8 +325,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                     if (!gok[c]) continue;
                     const size_t rix = (size_t)gpos[c] * B + (rb + 16 * c + gr);
                     if (J.sv) {
-                        float* sv = J.sv + (rix * HT + ht) * 64 + gn;
-                        sv[0] = o_r[c]; sv[16] = o_u[c]; sv[32] = o_n[c]; sv[48] = o_hn[c];
+                        *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(o_r[c], o_u[c], o_n[c], o_hn[c]);
                     }
                     if (J.hp) J.hp[rix * D + j] = o_hp[c];
                 }
@@ -409,8 +408,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                     const int len = J.reverse ? (one_sc ? len_g[c] : a.lens[row]) : 0;
                     rix[c] = pos_map(p, len, J.reverse) * B + row;
                     if (!(ab & 2)) {
-                        const float* sv = J.sv + ((size_t)rix[c] * HT + ht) * 64 + gn;
-                        s_r[c] = sv[0]; s_u[c] = sv[16]; s_n[c] = sv[32]; s_hn[c] = sv[48];
+                        const float4 sv = *reinterpret_cast<const float4*>(J.sv + ((size_t)rix[c] * HT + ht) * 64 + gn * 4);
+                        s_r[c] = sv.x; s_u[c] = sv.y; s_n[c] = sv.z; s_hn[c] = sv.w;
                         s_hp[c] = J.hp[(size_t)rix[c] * D + j];
                         if (J.dh_out) s_do[c] = J.dh_out[(size_t)rix[c] * a.ldh + j];
                     }
@@ -489,9 +488,9 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 const float dn = dH * (1.f - u) * (1.f - nn * nn);
                 const float du = dH * (s_hp[c] - nn) * u * (1.f - u);
                 const float dr = dn * s_hn[c] * r * (1.f - r);
-                float* dgh = J.dgh + (size_t)rix[c] * a.ldg + ht * 48 + gn;
-                if (fast) { dgh[0] = dr; dgh[16] = du; dgh[32] = dn * r; }                        // exchanged
-                else { store4_sc1(dgh, dr); store4_sc1(dgh + 16, du); store4_sc1(dgh + 32, dn * r); }
+                float* dgh = J.dgh + (size_t)rix[c] * a.ldg + ht * 48 + gn * 3;
+                if (fast) { dgh[0] = dr; dgh[1] = du; dgh[2] = dn * r; }                          // exchanged
+                else { store4_sc1(dgh, dr); store4_sc1(dgh + 1, du); store4_sc1(dgh + 2, dn * r); }
                 o_dr[c] = dr; o_du[c] = du; o_dn[c] = dn; o_car[c] = dH * u;
                 sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r;
             }
@@ -503,8 +502,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                     if (row >= row_end) continue;
                     J.carry[(size_t)row * D + j] = o_car[c];
                     if (!(ab & 4)) {
-                        float* dgi = J.dgi + (size_t)rix[c] * a.ldg + ht * 48 + gn;
-                        dgi[0] = o_dr[c]; dgi[16] = o_du[c]; dgi[32] = o_dn[c];
+                        float* dgi = J.dgi + (size_t)rix[c] * a.ldg + ht * 48 + gn * 3;
+                        dgi[0] = o_dr[c]; dgi[1] = o_du[c]; dgi[2] = o_dn[c];
                     }
                 }
             }
@@ -525,8 +524,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
         __syncthreads();
         if (tid < 48) {
             const int gate = tid >> 4, u = tid & 15;
-            if (J.dbW) atomicAdd(J.dbW + ht * 48 + gate * 16 + u, red[gate][u]);
-            if (J.dbR) atomicAdd(J.dbR + ht * 48 + gate * 16 + u, red[gate == 2 ? 3 : gate][u]);
+            if (J.dbW) atomicAdd(J.dbW + ht * 48 + u * 3 + gate, red[gate][u]);
+            if (J.dbR) atomicAdd(J.dbR + ht * 48 + u * 3 + gate, red[gate == 2 ? 3 : gate][u]);
         }
     }
 }

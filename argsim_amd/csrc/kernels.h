@@ -29,8 +29,9 @@ hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 
 // ---------------------------------------------------------------- GRU (gru.hip)
 // Gate-interleaved layout ("G16"): the 3D gate rows of W, R, bW, bR and the 3D columns of
-// gi / dgi / dgh are stored in the order  c' = ht*48 + gate*16 + u   (ht = unit/16, u = unit%16,
-// gate: 0=r 1=u 2=n) so that the 48 values one workgroup owns are contiguous.
+// gi / dgi / dgh are stored in the order  c' = ht*48 + u*3 + gate   (ht = unit/16, u = unit%16,
+// gate: 0=r 1=u 2=n) so that the 48 values one workgroup owns are contiguous and the three gates of
+// one unit are adjacent (one 12-byte access per thread in the gate phase).
 constexpr int kMaxGruJobs = 3;
 struct GruJob {
     const float* gi;      // + job column offset; row (pos*B + b) at gi + (pos*B+b)*ldg
@@ -38,7 +39,7 @@ struct GruJob {
     const float* bR;      // (3D) G16
     const float* h0;      // (B, D) or nullptr (zeros)
     float* hs;            // output, row (pos*B+b) at hs + (pos*B+b)*ldh (+ column offset applied)
-    float* sv;            // saved r,u,n,hn: (S,B,HT,4,16) or nullptr
+    float* sv;            // saved r,u,n,hn: (S,B,HT,16,4) or nullptr
     float* hp;            // saved h_prev (S,B,D) or nullptr
     int reverse;          // 1: time index map of tf.reverse_sequence (needs lens)
     // backward only

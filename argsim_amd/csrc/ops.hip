@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void g16_permute_kernel(float* __restrict__ ds
     const int64_t total = (int64_t)3 * D * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t row = i / cols; int col = (int)(i - row * cols);
-        // row is a G16 row index c' = ht*48 + gate*16 + u  <->  natural gate*D + ht*16 + u
-        int ht = (int)(row / 48), rem = (int)(row % 48), gate = rem / 16, u = rem % 16;
+        // row is a G16 row index c' = ht*48 + u*3 + gate  <->  natural gate*D + ht*16 + u
+        int ht = (int)(row / 48), rem = (int)(row % 48), u = rem / 3, gate = rem % 3;
         int64_t nat = (int64_t)gate * D + ht * 16 + u;
         if (to_g16) dst[i] = src[nat * cols + col];
         else dst[nat * cols + col] = src[i];
