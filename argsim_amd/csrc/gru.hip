@@ -148,6 +148,25 @@ __device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, in
     return s_fast != 0;
 }
 
+// blockIdx -> (job, group, hidden tile).  Under round-robin dispatch blocks b and b + grid/2 share a
+// CU (2 workgroups per CU): the map gives them DIFFERENT chains (the other direction, or another batch
+// group) so one's MFMA phase can overlap the other's exchange latency, keeps blockIdx % 8 = group % 8
+// (a group's workgroups on one XCD), and reports which half a block is in so that half can be
+// staggered by part of a step.  Any placement is correct; this is speed only.
+__device__ __forceinline__ bool wg_map(const GruArgs& a, int HT, int* jb, int* g, int* ht)
+{
+    const int per_job = a.G * HT, total = a.njobs * per_job, bid = blockIdx.x;
+    if (a.njobs == 1 && (a.G & 1) == 0 && a.G >= 2) {
+        const int halfn = total / 2, half = bid / halfn, r = bid - half * halfn, gh = a.G / 2;
+        *jb = 0; *g = (r % gh) + gh * half; *ht = r / gh;
+        return half != 0;
+    }
+    *jb = bid / per_job;
+    const int rem = bid - *jb * per_job;
+    *g = rem % a.G; *ht = rem / a.G;
+    return a.njobs == 2 && *jb == 1;
+}
+
 // ------------------------------------------------------------------------------ forward
 // Per step and workgroup: (1) issue the loads that do not depend on the exchange (gi);
 // (2) load the A operand = the group's h_{p-1} rows, re-loading until complete; (3) MFMAs;
@@ -163,9 +182,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kh = lane >> 4;
-    const int per_job = a.G * HT;
-    const int jb = blockIdx.x / per_job, rem = blockIdx.x - jb * per_job;
-    const int g = rem % a.G, ht = rem / a.G;
+    int jb, g, ht;
+    const bool second_half = wg_map(a, HT, &jb, &g, &ht);
     const GruJob& J = a.job[jb];
     const int B = a.B;
     const int row_beg = g * a.rows_per_group;
@@ -211,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     bool fast = false;
     if (a.p_end - a.p_begin > 1 && !(ab & 16))
         fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
+    if (second_half && a.p_end - a.p_begin > 1 && a.stagger > 0) __builtin_amdgcn_s_sleep(127);   // ~half a step
     int buf = 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_begin; p < a.p_end; ++p) {
@@ -357,9 +376,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kh = lane >> 4;
-    const int per_job = a.G * HT;
-    const int jb = blockIdx.x / per_job, rem = blockIdx.x - jb * per_job;
-    const int g = rem % a.G, ht = rem / a.G;
+    int jb, g, ht;
+    const bool second_half = wg_map(a, HT, &jb, &g, &ht);
     const GruJob& J = a.job[jb];
     const int B = a.B, S = a.S;
     const int row_beg = g * a.rows_per_group;
@@ -390,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     bool fast = false;
     if (a.p_end - 1 > p_last && !(ab & 16))
         fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
+    if (second_half && a.p_end - 1 > p_last && a.stagger > 0) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(64); }
     int buf = 0, done = 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {

@@ -76,6 +76,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gru-stagger', type=int, default=1)
     ap.add_argument('--gru-force-slow', action='store_true', help="never use the same-XCD L2 exchange path")
     ap.add_argument('--gru-ablate', type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument('--stepwise', action='store_true', help="one GRU launch per time step instead of the persistent kernels")
@@ -100,6 +101,7 @@ def main():
         dp.broadcast_params(model.state)
     if A.stepwise:
         model.set_option('persistent', 0)
+    model.set_option('gru_stagger', A.gru_stagger)
     if A.gru_force_slow:
         model.set_option('gru_force_slow', 1)
     if A.gru_ablate:
