@@ -94,9 +94,12 @@ def main():
     torch.cuda.set_device(local)
     dp = None
     model = VAE('train', device=local, seed=0, **CFG)
-    if world > 1:
+    if world > 1 or os.environ.get('AVAE_FORCE_DP') == '1':     # the env knob exercises the DP path on one GPU
         from argsim_amd.dist import DataParallel
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
         dp = DataParallel(model)
         dp.broadcast_params(model.state)
     if A.stepwise:
@@ -117,7 +120,7 @@ def main():
             model.train_step(ids, ids, seed=i)
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,7 +177,7 @@ def main():
             if not A.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

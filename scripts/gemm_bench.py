@@ -22,7 +22,11 @@ shapes = [  # name, a_mc, b_nc, M, N, K, split
     ('big TN 4096^2 x8192', 1, 1, 4096, 4096, 8192, 1),
     ('big NN 8192^2 x4096', 0, 1, 8192, 8192, 4096, 1),
 ]
-for name, a_mc, b_nc, M, N, K, split in shapes:
+variants = [int(x) for x in os.environ.get('VARIANTS', '0').split(',')]
+import itertools
+for (name, a_mc, b_nc, M, N, K, split), var in itertools.product(shapes, variants):
+    if var and split != 1: continue
+    if var: split = -var; name = name + ' v%d' % var
     A = torch.randn((K, M) if a_mc else (M, K), device=dev)
     B = torch.randn((K, N) if b_nc else (N, K), device=dev)
     Cm = torch.zeros((M, N), device=dev)
