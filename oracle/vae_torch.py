@@ -44,7 +44,7 @@ def _reverse_sequence(x, idx):
     return torch.gather(x, 0, idx.unsqueeze(-1).expand_as(x))
 
 
-def forward(P, cfg, src, tgt, mode='train', step=0, keep_mask=None, eps=None):
+def forward(P, cfg, src, tgt, mode='train', step=0, keep_mask=None, eps=None, kl_beta=1.0, free_bits=0.0):
     """P: dict of torch tensors.  Other arguments as ``vae_numpy.forward``.
     returns dict with loss, loss_gen, loss_kld, mu, lv, z, pred, per-sample arrays (torch tensors)."""
     D, L, eos, bos = cfg['dim_emb'], cfg['rnn_layers'], cfg['eos'], cfg['bos']
@@ -99,16 +99,18 @@ def forward(P, cfg, src, tgt, mode='train', step=0, keep_mask=None, eps=None):
         o['loss_gen_samp'] = torch.nn.functional.cross_entropy(logits, labels, reduction='none')
         o['loss_gen'] = o['loss_gen_samp'].mean()
         o['loss_kld_samp'] = 0.5 * (mu * mu + torch.exp(lv) - lv - 1.0)
-        o['loss_kld'] = o['loss_kld_samp'].mean()
-        o['loss'] = anneal * o['loss_kld'] + o['loss_gen']
+        # extensions of BASELINE configs[4] (not in the reference): per-dimension KL floor and a beta factor;
+        # at (1, 0) this is exactly model.py:183-185
+        o['loss_kld'] = torch.clamp(o['loss_kld_samp'], min=free_bits).mean() if free_bits > 0 else o['loss_kld_samp'].mean()
+        o['loss'] = kl_beta * anneal * o['loss_kld'] + o['loss_gen']
         o['errt_samp'] = (labels != o['pred']).to(dt)
     return o
 
 
-def loss_and_grads(P_np, cfg, src, tgt, step, keep_mask, eps, dtype=torch.float64):
+def loss_and_grads(P_np, cfg, src, tgt, step, keep_mask, eps, dtype=torch.float64, kl_beta=1.0, free_bits=0.0):
     """float64 gradient oracle: returns (outputs dict of numpy, grads dict of numpy)."""
     P = to_torch(P_np, dtype)
-    o = forward(P, cfg, src, tgt, 'train', step, keep_mask, eps)
+    o = forward(P, cfg, src, tgt, 'train', step, keep_mask, eps, kl_beta, free_bits)
     o['loss'].backward()
     grads = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in P.items()}
     outs = {k: v.detach().numpy() for k, v in o.items()}
