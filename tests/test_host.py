@@ -166,3 +166,39 @@ def test_synthetic_batches():
     lens = (r != 1).sum(1)
     assert lens.min() >= 2 and lens.max() <= 64 and (lens < 64).any()
     assert np.array_equal(a, synth.batch(16, 12, 8192, seed=0))
+
+
+def test_data_prep_ibm_and_iac(tmp_path):
+    """counterparts of data_ibm.py / data_iac.py on synthetic corpora of the same file shapes"""
+    import csv, json
+    from argsim_amd import data_prep
+    rng = np.random.default_rng(1)
+    words = ['claim', 'evidence', 'topic', 'we', 'should', 'ban', 'allow', 'the', 'of', 'because', 'people', 'rights', 'law']
+    def sent(): return ' '.join(rng.choice(words, int(rng.integers(4, 10)))).capitalize() + '.'
+    src = tmp_path / 'ibm'; src.mkdir()
+    n = 0
+    for split in data_prep.IBM_SPLITS:
+        with open(src / split, 'w', newline='') as f:
+            w = csv.writer(f); w.writerow(['id', 'topic', 'x', 'claim'])
+            for _ in range(30):
+                w.writerow([n, 't', 'x', sent()]); n += 1
+    out = tmp_path / 'out_ibm'
+    v = data_prep.prep_ibm(str(src), str(out), valid_size=20, vocab_size=32)
+    valid = np.load(out / 'valid.npy')
+    train = open(out / 'train.txt').read().splitlines()
+    assert valid.shape[0] == 20 and valid.dtype == np.int32 and len(train) == n - 20
+    sents = open(out / 'all.txt').read().splitlines()
+    np.random.seed(0); ref = list(sents); np.random.shuffle(ref)          # the reference's exact shuffle
+    assert train == ref[20:]
+    raw = tmp_path / 'iac'; raw.mkdir()
+    for i in range(3):
+        posts = [[j, 'side', 'author', '  %s\n %s ' % (sent(), sent()), [], None, 'cat', 0] for j in range(10)] + [[99, 's', 'a', '   ', [], None, 'c', 0]]
+        json.dump([posts, {}, {}], open(raw / ('%d.json' % i), 'w'))
+    open(tmp_path / 'val.txt', 'w').write('\n'.join(sent() + ' ' + sent() for _ in range(7)) + '\n')
+    out2 = tmp_path / 'out_iac'
+    v2 = data_prep.prep_iac(str(raw), str(tmp_path / 'val.txt'), str(out2), cap=16, vocab_size=32)
+    valid2 = np.load(out2 / 'valid.npy')
+    assert valid2.shape == (7, 16) and (valid2[:, -1] == v2.eos_id()).all()
+    lines = open(out2 / 'train.txt').read().splitlines()
+    assert len(lines) == 30                                                 # the empty post was dropped
+    assert all(len(v2.encode_as_ids(l)) <= 16 for l in lines) and all(l == l.lower() for l in lines)
