@@ -173,7 +173,8 @@ def test_data_prep_ibm_and_iac(tmp_path):
     import csv, json
     from argsim_amd import data_prep
     rng = np.random.default_rng(1)
-    words = ['claim', 'evidence', 'topic', 'we', 'should', 'ban', 'allow', 'the', 'of', 'because', 'people', 'rights', 'law']
+    words = ['claim', 'evidence', 'topic', 'we', 'should', 'ban', 'allow', 'the', 'of', 'because', 'people', 'rights', 'law',
+             'government', 'school', 'marriage', 'justify', 'question', 'believe', 'liberty', 'zoning', 'tax', 'vote', 'health', 'market']
     def sent(): return ' '.join(rng.choice(words, int(rng.integers(4, 10)))).capitalize() + '.'
     src = tmp_path / 'ibm'; src.mkdir()
     n = 0
@@ -183,7 +184,15 @@ def test_data_prep_ibm_and_iac(tmp_path):
             for _ in range(30):
                 w.writerow([n, 't', 'x', sent()]); n += 1
     out = tmp_path / 'out_ibm'
-    v = data_prep.prep_ibm(str(src), str(out), valid_size=20, vocab_size=32)
+    def fit(fn):
+        # SentencePiece accepts only a narrow vocabulary range on a toy corpus: take the first size that trains
+        for size in (64, 60, 56, 52, 50, 48, 46, 44, 42, 40):
+            try:
+                return fn(size)
+            except RuntimeError:
+                continue
+        raise AssertionError("no trainable vocabulary size")
+    v = fit(lambda size: data_prep.prep_ibm(str(src), str(out), valid_size=20, vocab_size=size))
     valid = np.load(out / 'valid.npy')
     train = open(out / 'train.txt').read().splitlines()
     assert valid.shape[0] == 20 and valid.dtype == np.int32 and len(train) == n - 20
@@ -196,7 +205,7 @@ def test_data_prep_ibm_and_iac(tmp_path):
         json.dump([posts, {}, {}], open(raw / ('%d.json' % i), 'w'))
     open(tmp_path / 'val.txt', 'w').write('\n'.join(sent() + ' ' + sent() for _ in range(7)) + '\n')
     out2 = tmp_path / 'out_iac'
-    v2 = data_prep.prep_iac(str(raw), str(tmp_path / 'val.txt'), str(out2), cap=16, vocab_size=32)
+    v2 = fit(lambda size: data_prep.prep_iac(str(raw), str(tmp_path / 'val.txt'), str(out2), cap=16, vocab_size=size))
     valid2 = np.load(out2 / 'valid.npy')
     assert valid2.shape == (7, 16) and (valid2[:, -1] == v2.eos_id()).all()
     lines = open(out2 / 'train.txt').read().splitlines()
