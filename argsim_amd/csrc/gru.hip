@@ -581,36 +581,46 @@ static hipError_t check(const GruArgs& a, int* grid)
     return hipSuccess;
 }
 
-// sentinel fill of an exchanged buffer region: rows x width floats at row stride ld
-static hipError_t fill_sentinel(hipStream_t st, float* base, size_t rows, size_t width, size_t ld)
+// One launch prepares a persistent run: zero the sync words and fill the exchanged buffer with the
+// sentinel (a plain kernel: hipMemsetAsync goes through the blit path and costs ~10 us of stream gap).
+__global__ __launch_bounds__(256) void gru_prepare_kernel(unsigned* sync_words, int nsync, uint4* buf, size_t n16)
 {
-    if (width == ld) return hipMemsetAsync(base, 0xFF, rows * ld * sizeof(float), st);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)nsync) sync_words[i] = 0u;
+    const uint4 s4 = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+    for (; i < n16; i += stride) buf[i] = s4;
+}
+static hipError_t fill_sentinel2d(hipStream_t st, float* base, size_t rows, size_t width, size_t ld)
+{
     return hipMemset2DAsync(base, ld * sizeof(float), 0xFF, width * sizeof(float), rows, st);
 }
 
-// sentinel-fill the exchanged buffer of every job; jobs that tile whole rows side by side (the two
-// encoder directions) are covered by ONE linear fill instead of strided 2-D fills
-static hipError_t fill_exchange(hipStream_t st, const GruArgs& a, bool fwd)
+// sentinel-fill the exchanged buffer of every job and zero the sync words; jobs that tile whole rows side
+// by side (the two encoder directions) are covered by ONE linear fill
+static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd)
 {
     const size_t rows = (size_t)a.S * a.B, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
     float* base0 = fwd ? a.job[0].hs : a.job[0].dgh;
-    bool side_by_side = (size_t)a.njobs * width == ld;
+    bool side_by_side = (size_t)a.njobs * width == ld && (((uintptr_t)base0) & 15) == 0 && ((rows * ld) & 3) == 0;
     for (int i = 0; i < a.njobs && side_by_side; ++i)
         side_by_side = (fwd ? a.job[i].hs : a.job[i].dgh) == base0 + i * width;
-    if (side_by_side) return fill_sentinel(st, base0, rows, ld, ld);
-    for (int i = 0; i < a.njobs; ++i) {
-        hipError_t e = fill_sentinel(st, fwd ? a.job[i].hs : a.job[i].dgh, rows, width, ld);
-        if (e != hipSuccess) return e;
+    if (side_by_side) {
+        hipLaunchKernelGGL(gru_prepare_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords,
+                           reinterpret_cast<uint4*>(base0), rows * ld / 4);
+        return hipGetLastError();
     }
-    return hipSuccess;
+    hipError_t e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st);
+    for (int i = 0; i < a.njobs && e == hipSuccess; ++i)
+        e = fill_sentinel2d(st, fwd ? a.job[i].hs : a.job[i].dgh, rows, width, ld);
+    return e;
 }
 
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
-        e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
-        e = fill_exchange(st, a, true); if (e != hipSuccess) return e;
+        e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
         return launch<true>(st, a, grid);
     }
     for (int p = a.p_begin; p < a.p_end; ++p) {
@@ -624,8 +634,7 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
-        e = hipMemsetAsync(a.counters, 0, sizeof(unsigned) * kGruSyncWords, st); if (e != hipSuccess) return e;
-        e = fill_exchange(st, a, false); if (e != hipSuccess) return e;
+        e = prepare_exchange(st, a, false); if (e != hipSuccess) return e;
         return launch<false>(st, a, grid);
     }
     // one launch per step (descending); the dh0 tail (p = -1) is its own launch

@@ -82,6 +82,7 @@ struct PrepArgs {
     int32_t* rank;      // (St+1,B) compact row of (t,b) or -1
     int32_t* cidx;      // (N) flat (t*B+b) of compact row
     int32_t* ntok;      // [0]=N
+    float* zero2;       // optional: two floats cleared here (the loss accumulators), saves a memset launch
 };
 hipError_t prep_ids(hipStream_t st, const PrepArgs& p);
 

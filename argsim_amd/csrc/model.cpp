@@ -63,7 +63,7 @@ struct avae_ctx {
     // last forward geometry
     int B = 0, Ss = 0, St = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
-    int timing = 0;
+    int timing = 0, timing_on = 0;
     struct Stamp { hipEvent_t a, b; int cls; double flops; };
     std::vector<Stamp> stamps; size_t stamps_used = 0;
 };
@@ -350,12 +350,11 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
     const int T = St + 1, rt = T * B;
     Sched sc = schedule(h);
-    AV_CHECK(hipMemsetAsync(h->acc, 0, 2 * sizeof(float), h->stream));
     PrepArgs p{};
     p.src = src; p.tgt = tgt; p.B = B; p.Ss = Ss; p.St = St; p.eos = h->cfg.eos; p.bos = h->cfg.bos;
     p.train = train ? 1 : 0; p.keepwd = sc.keepwd; p.seed = seed; p.keep_mask = keep_mask;
     p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
-    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok;
+    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.zero2 = h->acc;
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
@@ -683,7 +682,8 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_stagger")) { h->gru_stagger = value; return 0; }
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_ablate")) { h->gru_ablate = value; return 0; }
-    if (!strcmp(key, "timing")) { h->timing = value; h->stamps_used = 0; return 0; }
+    if (!strcmp(key, "timing")) { h->timing = value; h->timing_on = value; h->stamps_used = 0; return 0; }
+    if (!strcmp(key, "timing_pause")) { h->timing = value ? 0 : h->timing_on; return 0; }
     return fail(h, "unknown option");
 }
 // synchronises, sums the HIP-event durations recorded since timing was switched on / last collected:

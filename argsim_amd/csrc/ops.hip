@@ -83,6 +83,7 @@ __global__ __launch_bounds__(1024) void prep_ids_kernel(PrepArgs p)
         if (m) p.cidx[run++] = i;
     }
     if (tid == 1023) p.ntok[0] = sums[1023];
+    if (tid < 2 && p.zero2) p.zero2[tid] = 0.f;
 }
 hipError_t prep_ids(hipStream_t st, const PrepArgs& p)
 {
