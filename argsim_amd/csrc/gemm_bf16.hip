@@ -1,0 +1,234 @@
+// gemm_bf16.hip -- bf16-operand GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 output) plus
+// the conversion kernels that bring fp32 operands into k-contiguous bf16 panels.
+//
+// This is the opt-in precision mode of BASELINE.json configs[2] ("bf16 ... MFMA vocab-projection GEMM"):
+// every dense contraction of the step (input projections, out affine, tied logits and all their
+// gradients) rounds its two operands to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) and accumulates
+// in fp32; parameters, activations, the recurrent state, the gate math, the losses and Adam stay fp32.
+// The default mode is exact fp32 (gemm_f32.hip); nothing here runs unless compute_dtype = 1.
+//
+// One GEMM layout only: C[M,N] = alpha * A[M,K] * B[N,K]^T with both operands k-contiguous bf16.  fp32
+// operands that are stored [k][x] (the NN / TN cases of the fp32 kernel) are transposed while they are
+// converted, so the GEMM never needs a transposing LDS access.
+#include "kernels.h"
+
+namespace avae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// ---------------------------------------------------------------- fp32 [rows][cols] -> bf16 [rows][ldd]
+// ldd = cols rounded up to 8; the pad columns are written as zeros.  One thread = 8 output elements.
+__global__ __launch_bounds__(256) void cvt_rows_bf16_kernel(const float* __restrict__ src, int ld, int rows, int cols,
+                                                            unsigned short* __restrict__ dst, int ldd)
+{
+    const int groups = ldd >> 3;
+    const size_t total = (size_t)rows * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / groups), c = (int)(i - (size_t)r * groups) << 3;
+        const float* s = src + (size_t)r * ld + c;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (c + 4 * q + 4 <= cols) {
+                float4 t = *reinterpret_cast<const float4*>(s + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = (c + 4 * q + e < cols) ? s[4 * q + e] : 0.f;
+            }
+        }
+        uint4 o = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------- fp32 [K][X] -> bf16 [X][ldk] (transpose)
+// 64x64 tiles through LDS; ldk = K rounded up to 8, pad written as zeros.
+__global__ __launch_bounds__(256) void cvt_transpose_bf16_kernel(const float* __restrict__ src, int ld, int K, int X,
+                                                                 unsigned short* __restrict__ dst, int ldk)
+{
+    __shared__ float tile[64][65];
+    const int k0 = blockIdx.y * 64, x0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        int f = tid + 256 * rep, k = f >> 4, xq = (f & 15) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + k < K && x0 + xq < X) v = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + x0 + xq);
+        tile[k][xq] = v.x; tile[k][xq + 1] = v.y; tile[k][xq + 2] = v.z; tile[k][xq + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        int f = tid + 256 * rep, x = f & 63, kg = (f >> 6) << 3;
+        if (x0 + x < X && k0 + kg < ldk) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[kg + e][x];       // rows beyond K were loaded as zeros
+            uint4 o = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            *reinterpret_cast<uint4*>(dst + (size_t)(x0 + x) * ldk + k0 + kg) = o;
+        }
+    }
+}
+
+hipError_t cvt_bf16(hipStream_t st, const float* src, int ld, bool transpose, int rows_or_K, int cols_or_X,
+                    unsigned short* dst, int ldd)
+{
+    if (!transpose) {
+        size_t total = (size_t)rows_or_K * (ldd >> 3);
+        unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, ld, rows_or_K, cols_or_X, dst, ldd);
+    } else {
+        dim3 grid((cols_or_X + 63) / 64, (ldd + 63) / 64);
+        hipLaunchKernelGGL(cvt_transpose_bf16_kernel, grid, dim3(256), 0, st, src, ld, rows_or_K, cols_or_X, dst, ldd);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- the GEMM
+// Block tile 128x128x64, 4 waves (2x2), each 2x2 MFMA tiles of 32x32; operand lane map of
+// v_mfma_f32_32x32x16_bf16: lane l (r = l&31, h = l>>5) holds A[r][k = 8h + j], B[k = 8h + j][r], j = 0..7,
+// i.e. one ds_read_b128 per operand tile and k-step.  LDS row stride 72 bf16 = 36 dwords (conflict free).
+constexpr int BKH = 64, LDH = BKH + 8;
+
+__device__ __forceinline__ void load_panel(uint4 (&r)[4], const unsigned short* __restrict__ P, int ld, int x0, int X,
+                                           int k0, int K, int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        int f = tid + 256 * rep, x = x0 + (f >> 3), k = k0 + ((f & 7) << 3);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (x < X && k < K) {
+            v = *reinterpret_cast<const uint4*>(P + (size_t)x * ld + k);
+            if (k + 8 > K) {            // K tail inside this vector (device-side K): drop the elements >= K
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k + e >= K) w[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        r[rep] = v;
+    }
+}
+__device__ __forceinline__ void store_panel(unsigned short* __restrict__ s, const uint4 (&r)[4], int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        int f = tid + 256 * rep;
+        *reinterpret_cast<uint4*>(s + (f >> 3) * LDH + ((f & 7) << 3)) = r[rep];
+    }
+}
+
+struct GemmBf16Args {
+    const unsigned short* A; const unsigned short* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    float alpha; int accumulate, split_k; const int* dyn; int dyn_kind;
+};
+
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBf16Args g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 128 * LDH];
+    unsigned short* As = smem;
+    unsigned short* Bs = smem + 128 * LDH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int M = g.M, K = g.K;
+    if (g.dyn_kind == 1) M = min(M, *g.dyn);
+    if (g.dyn_kind == 2) K = min(K, *g.dyn);
+    const int tiles_n = (g.N + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    if (m0 >= M) return;
+    int kb = 0, ke = K;
+    if (g.split_k > 1) {
+        int ktiles = (K + BKH - 1) / BKH, per = (ktiles + g.split_k - 1) / g.split_k;
+        kb = blockIdx.z * per * BKH; ke = min(K, kb + per * BKH);
+        if (kb >= ke) return;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    load_panel(ra, g.A, g.lda, m0, M, kb, ke, tid);
+    load_panel(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    for (int k0 = kb; k0 < ke; k0 += BKH) {
+        store_panel(As, ra, tid);
+        store_panel(Bs, rb, tid);
+        __syncthreads();
+        if (k0 + BKH < ke) {
+            load_panel(ra, g.A, g.lda, m0, M, k0 + BKH, ke, tid);
+            load_panel(rb, g.B, g.ldb, n0, g.N, k0 + BKH, ke, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (64 * wm + 32 * t + l31) * LDH + 16 * s + 8 * h));
+                b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (64 * wn + 32 * t + l31) * LDH + 16 * s + 8 * h));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const bool atomic = g.split_k > 1;
+    const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int col = n0 + 64 * wn + 32 * j + l31;
+        if (col >= g.N) continue;
+        float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+// operands already converted: A [M][lda] bf16, B [N][ldb] bf16, lda/ldb multiples of 8
+hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g)
+{
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if ((lda | ldb) & 7) return hipErrorInvalidValue;
+    GemmBf16Args a{A, B, g.C, g.bias, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, g.accumulate, g.split_k, g.dyn, g.dyn_kind};
+    int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace avae

@@ -27,6 +27,14 @@ struct GemmArgs {
 };
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 
+// ---------------------------------------------------------------- bf16-operand GEMM (gemm_bf16.hip)
+// fp32 -> bf16 panel: transpose == false: src [rows][cols] (ld) -> dst [rows][ldd];  transpose == true:
+// src [K][X] (ld) -> dst [X][ldd] with ldd >= K.  ldd is a multiple of 8; pad columns are zero filled.
+hipError_t cvt_bf16(hipStream_t st, const float* src, int ld, bool transpose, int rows_or_K, int cols_or_X,
+                    unsigned short* dst, int ldd);
+// C = alpha * A B^T (+bias)(+C): A [M][lda], B [N][ldb] bf16 k-contiguous; the other fields as in GemmArgs
+hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);
+
 // ---------------------------------------------------------------- GRU (gru.hip)
 // Gate-interleaved layout ("G16"): the 3D gate rows of W, R, bW, bR and the 3D columns of
 // gi / dgi / dgh are stored in the order  c' = ht*48 + u*3 + gate   (ht = unit/16, u = unit%16,

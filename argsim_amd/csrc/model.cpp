@@ -64,6 +64,8 @@ struct avae_ctx {
     int B = 0, Ss = 0, St = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     int timing = 0, timing_on = 0;
+    // bf16-operand GEMM mode (compute_dtype = 1): converted operand panels
+    unsigned short *bfA = nullptr, *bfB = nullptr; size_t bfA_cap = 0, bfB_cap = 0;
     struct Stamp { hipEvent_t a, b; int cls; double flops; };
     std::vector<Stamp> stamps; size_t stamps_used = 0;
 };
@@ -185,12 +187,34 @@ int get_ws(avae_ctx* h, Ws& w, int B, int Ss, int St, bool train)
 }
 
 // -------------------------------------------------------------------------------- helpers
+int grow_bf16(avae_ctx* h, unsigned short** buf, size_t* cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    if (*buf) AV_CHECK(hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    size_t n = need + need / 8;
+    AV_CHECK(hipMalloc(reinterpret_cast<void**>(buf), n * sizeof(unsigned short)));
+    *cap = n;
+    return 0;
+}
+
 int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
              int M, int N, int K, float alpha, const float* bias, int accumulate, int split_k, const int* dyn, int dyn_kind,
              int thin = 0)
 {
     GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin};
     Timed t(h, 0, 2.0 * M * N * K);
+    if (h->cfg.compute_dtype == 1) {
+        // bf16 operands: convert (transposing [k][x] operands) into k-contiguous panels, then one NT kernel
+        const int Kp = (K + 7) & ~7;
+        AV_TRY(grow_bf16(h, &h->bfA, &h->bfA_cap, (size_t)M * Kp));
+        AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)N * Kp));
+        AV_CHECK(cvt_bf16(h->stream, A, lda, a_mc, a_mc ? K : M, a_mc ? M : K, h->bfA, Kp));
+        AV_CHECK(cvt_bf16(h->stream, Bm, ldb, b_nc, b_nc ? K : N, b_nc ? N : K, h->bfB, Kp));
+        AV_CHECK(gemm_bf16_nt(h->stream, h->bfA, Kp, h->bfB, Kp, g));
+        return 0;
+    }
     AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
     return 0;
 }
@@ -573,6 +597,7 @@ int avae_create(const avae_config* cfg, int device, avae_handle* out)
     if (!cfg || !out) { g_create_err = "null argument"; return 1; }
     *out = nullptr;
     if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 64, 256, 512"; return 1; }
+    if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { g_create_err = "compute_dtype must be 0 (fp32) or 1 (bf16 GEMM operands)"; return 1; }
     if (cfg->dim_rep % 4 || cfg->dim_tgt % 4 || cfg->rnn_layers < 1 || cfg->rnn_layers > 8) { g_create_err = "dim_rep and dim_tgt must be multiples of 4; 1 <= rnn_layers <= 8"; return 1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available: the gfx950 kernels cannot run (no CPU fallback)"; return 1; }
@@ -604,6 +629,8 @@ void avae_destroy(avae_handle h)
     if (h->errw) (void)hipFree(h->errw);
     if (h->counters) (void)hipFree(h->counters);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->bfA) (void)hipFree(h->bfA);
+    if (h->bfB) (void)hipFree(h->bfB);
     delete h;
 }
 

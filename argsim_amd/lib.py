@@ -14,7 +14,8 @@ CSRC = os.path.join(_HERE, 'csrc')
 class AvaeConfig(C.Structure):
     _fields_ = [('dim_tgt', C.c_int32), ('dim_emb', C.c_int32), ('dim_rep', C.c_int32), ('rnn_layers', C.c_int32),
                 ('accelerate', C.c_float), ('learn_rate', C.c_float), ('bos', C.c_int32), ('eos', C.c_int32),
-                ('max_batch', C.c_int32), ('max_len', C.c_int32), ('kl_beta', C.c_float), ('free_bits', C.c_float)]
+                ('max_batch', C.c_int32), ('max_len', C.c_int32), ('kl_beta', C.c_float), ('free_bits', C.c_float),
+                ('compute_dtype', C.c_int32)]
 
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int64)

@@ -36,7 +36,7 @@ class VAE:
     def __init__(self, mode='train', device=0, dim_tgt=8192, dim_emb=512, dim_rep=1024, rnn_layers=3,
                  bidirectional=True, bidir_stacked=True, attentive=False, logit_use_embed=True,
                  accelerate=1e-4, learn_rate=1e-3, bos=2, eos=1, kl_beta=1.0, free_bits=0.0,
-                 seed=0, init=True):
+                 seed=0, init=True, dtype='f32'):
         assert mode in ('train', 'valid', 'infer')          # model.py:72
         _check_cfg(bidirectional, bidir_stacked, attentive, logit_use_embed)
         if not torch.cuda.is_available():
@@ -46,7 +46,10 @@ class VAE:
                         accelerate=accelerate, learn_rate=learn_rate, bos=bos, eos=eos)
         self._l = _lib.load()
         self.device = torch.device('cuda', device)
-        c = _lib.AvaeConfig(dim_tgt, dim_emb, dim_rep, rnn_layers, accelerate, learn_rate, bos, eos, 0, 0, kl_beta, free_bits)
+        assert dtype in ('f32', 'bf16'), "dtype: 'f32' (exact, reference) or 'bf16' (bf16 GEMM operands, fp32 everything else)"
+        self.dtype = dtype
+        c = _lib.AvaeConfig(dim_tgt, dim_emb, dim_rep, rnn_layers, accelerate, learn_rate, bos, eos, 0, 0, kl_beta, free_bits,
+                            1 if dtype == 'bf16' else 0)
         h = C.c_void_p()
         if self._l.avae_create(C.byref(c), device, C.byref(h)):
             raise RuntimeError("avae_create: " + self._l.avae_last_error(None).decode())

@@ -76,6 +76,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'),
+                    help="f32 = the reference's precision (headline); bf16 = bf16 GEMM operands, fp32 everything else")
     ap.add_argument('--no-timing', action='store_true', help="skip the per-kernel HIP-event stamps (roofline leg)")
     ap.add_argument('--gru-stagger', type=int, default=1)
     ap.add_argument('--gru-force-slow', action='store_true', help="never use the same-XCD L2 exchange path")
@@ -94,7 +96,7 @@ def main():
     assert world == A.gpus, "launch with torch.distributed.run --nproc-per-node %d" % A.gpus
     torch.cuda.set_device(local)
     dp = None
-    model = VAE('train', device=local, seed=0, **CFG)
+    model = VAE('train', device=local, seed=0, dtype=A.dtype, **CFG)
     if world > 1 or os.environ.get('AVAE_FORCE_DP') == '1':     # the env knob exercises the DP path on one GPU
         from argsim_amd.dist import DataParallel
         if not dist.is_initialized():
@@ -156,9 +158,11 @@ def main():
         out = {
             "metric": "sentences/sec per ELBO step", "value": world * B * A.steps / dt, "unit": "sentences/sec",
             "n_gpus": world, "steps": A.steps, "warmup": A.warmup, "ms_per_step": 1e3 * dt / A.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1xMI355X fp32, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
-                                   "FULL synthetic Zipf batches, dim_emb 512, 3 layers, step 20000",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if A.dtype == 'f32' else "bf16 GEMM operands, f32 accumulate/recurrence/state/Adam", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1xMI355X %s, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
+                                   "FULL synthetic Zipf batches, dim_emb 512, 3 layers, step 20000"
+                                   % ("fp32" if A.dtype == 'f32' else "(bf16 GEMM operands: the opt-in mode of configs[2], same shapes)"),
                        "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
                        "gru": "stepwise" if A.stepwise else "persistent"},
             "loss": losses[2],
@@ -178,8 +182,9 @@ def main():
                     traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+            peak = PEAK_F32_MFMA if (A.dtype == 'f32' or name != 'gemm') else 2500.0
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                                "flops_per_launch": fl / max(n, 1),
                                "launches_per_step": n / nst, "avg_launch_ms": ms / max(n, 1), "stamped_steps": nst,
                                "share_of_step": ms / total_ms,

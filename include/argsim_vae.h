@@ -45,6 +45,8 @@ typedef struct avae_config {
     /* extensions (not in the reference; identity at beta=1, free_bits=0) */
     float   kl_beta;      /* multiplies rate_anneal            */
     float   free_bits;    /* per-dimension KL floor (nats)     */
+    int32_t compute_dtype;/* 0 = exact fp32 (reference);       */
+                          /* 1 = bf16 GEMM operands, fp32 accumulate/state/weights (BASELINE configs[2]) */
 } avae_config;
 
 /* kind selector for avae_get_tensor / avae_set_tensor */

@@ -44,7 +44,7 @@ def test_create_fails_loudly_without_gpu():
         pytest.skip("a GPU is present")
     from argsim_amd import lib
     l = lib.load()
-    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0)
+    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 0)
     h = ctypes.c_void_p()
     assert l.avae_create(ctypes.byref(cfg), 0, ctypes.byref(h)) != 0
     assert b'no CPU fallback' in l.avae_last_error(None) or b'HIP' in l.avae_last_error(None)

@@ -44,7 +44,7 @@ def test_gemm(a_mc, b_nc, M, N, K):
     bias = rng.standard_normal(N).astype(np.float32)
     C0 = rng.standard_normal((M, N)).astype(np.float32)
     ref = 0.5 * (A.astype(np.float64) @ B.astype(np.float64)) + bias
-    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0)
+    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 0)
     h = C.c_void_p()
     assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
     dev = torch.device('cuda', 0)
@@ -395,3 +395,60 @@ def test_training_driver_end_to_end(tmp_path):
     assert all(np.isfinite([r['step_errt'], r['step_loss_gen'], r['step_loss_kld']]).all() for r in recs)
     assert recs[1]['step_loss_gen'] < recs[0]['step_loss_gen']          # it learns
     assert (d / 'ckpt' / 't0.npz').exists()                              # <trial><step // 10000>, src/train.py:121
+
+
+# ---------------------------------------------------------------- bf16 GEMM-operand mode (BASELINE configs[2])
+@pytest.mark.parametrize("a_mc,b_nc", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 52), (333, 260, 132), (64, 512, 1000)])
+def test_gemm_bf16_operands(a_mc, b_nc, M, N, K):
+    """bf16 mode: operands rounded to bf16 (RNE), products accumulated in fp32.  Against float64 products of the
+    SAME rounded operands the only error left is fp32 accumulation order."""
+    import torch
+    from argsim_amd import lib
+    l = lib.load()
+    if a_mc:
+        M = (M + 3) // 4 * 4
+    if b_nc:
+        N = (N + 3) // 4 * 4
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    Ar = torch.tensor(A).to(torch.bfloat16).to(torch.float64).numpy()
+    Br = torch.tensor(B).to(torch.bfloat16).to(torch.float64).numpy()
+    ref = 0.5 * (Ar @ Br) + bias
+    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 1)
+    h = C.c_void_p()
+    assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
+    dev = torch.device('cuda', 0)
+    At = torch.tensor(A.T.copy() if a_mc else A, device=dev)
+    Bt = torch.tensor(B if b_nc else B.T.copy(), device=dev)
+    bt = torch.tensor(bias, device=dev)
+    for acc, split in ((0, 1), (0, 3)):
+        Ct = torch.zeros((M, N), device=dev)
+        rc = l.avae_debug_gemm(h, a_mc, b_nc, At.data_ptr(), Bt.data_ptr(), Ct.data_ptr(), bt.data_ptr(),
+                               M, N, K, M if a_mc else K, N if b_nc else K, N, 0.5, acc, split)
+        assert rc == 0, l.avae_last_error(h)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), (acc, split)
+    l.avae_destroy(h)
+
+
+@pytest.mark.parametrize("name", ['mid', 'wide', 'full2'])
+def test_bf16_mode_tracks_the_oracle(name):
+    """whole path with bf16 GEMM operands (fp32 accumulate, fp32 recurrence / state / Adam): stated bf16
+    tolerances -- z <= 3e-2 abs, losses <= 1e-2 rel, gradients <= 5e-2 relative L2 per variable"""
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P, dtype='bf16')
+    o = vn.forward(P, cfg, ids, ids, 'valid')
+    z = m.encode(ids)
+    assert np.abs(z - o['mu']).max() <= 3e-2
+    m.step = 20000
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    lg, lk, lo = m.losses()
+    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, 20000, keep, eps)
+    assert abs(lo - outs['loss']) <= 1e-2 * abs(outs['loss'])
+    got = m.get_grads()
+    bad = {k: rel_l2(got[k], grads[k]) for k in grads if rel_l2(got[k], grads[k]) > 5e-2}
+    assert not bad, bad
