@@ -48,7 +48,8 @@ __device__ __forceinline__ int kperm(int ks, int kh)
 }
 
 // diagnostic phase stamps (ablate bit 32): 100 MHz real-time counter deltas summed per workgroup
-#define AVAE_STAMP(i) do { if (ab & 32) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
+// (compile-time: the production instantiation carries no stamp code at all)
+#define AVAE_STAMP(i) do { if constexpr (STAMPS) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
 
 __device__ __forceinline__ u32x4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off)
 {
@@ -107,6 +108,34 @@ __device__ __forceinline__ void load_frag(float* dst, __amdgpu_buffer_rsrc_t rs,
         }
     }
 }
+// Pipelined form: the loads of a fragment are ISSUED (no wait) and the fragment is verified later, at its
+// first use.  Written so that hipcc's waitcnt insertion stays counted on the fast path: younger fragments
+// issued in straight-line code before the check stay in flight (vmcnt(N)); only the rare re-load loop,
+// which consumes what it loads inside the loop, waits for everything.
+template <int NQ>
+__device__ __forceinline__ void frag_issue(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = load16_sc1(rs, off + 64u * q);
+}
+template <int NQ>
+__device__ __forceinline__ bool frag_bad(const u32x4 (&v)[NQ])
+{
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bad |= (v[q].x == kSentinel) | (v[q].y == kSentinel) | (v[q].z == kSentinel) | (v[q].w == kSentinel);
+    return __any(bad);
+}
+// verify `v`; on sentinels re-load it until complete (bounded)
+template <int NQ>
+__device__ __forceinline__ void frag_ensure(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_t rs, unsigned off, int* err)
+{
+    if (frag_bad<NQ>(v)) {
+        SpinGuard sg;
+        do { frag_issue<NQ>(v, rs, off); } while (frag_bad<NQ>(v) && !sg.expired(err));
+    }
+}
+
 // scalar-element variant for the small test dimensions (wave K range not a multiple of 16)
 template <int N, int NKS>
 __device__ __forceinline__ void load_frag_scalar(float* dst, const float* base, int ks0, int kh, bool poll, int* err)
@@ -172,7 +201,7 @@ __device__ __forceinline__ bool wg_map(const GruArgs& a, int HT, int* jb, int* g
 // (2) load the A operand = the group's h_{p-1} rows, re-loading until complete; (3) MFMAs;
 // (4) K-split partial sums and the workgroup's own h_{p-1} slice meet in LDS (the only barrier of
 // the step); (5) gate math; (6) store h_p (the exchanged data) first, then the saved gates.
-template <int KS>   // D = 16*KS
+template <int KS, bool STAMPS>   // D = 16*KS
 __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 {
     constexpr int D = 16 * KS, HT = KS;
@@ -254,33 +283,51 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 }
             }
             AVAE_STAMP(0);
-            // (2) A operand = h_{p-1} of the group's rows, this wave's K quarter
-            float av[2][KS];
+            // (2) A operand = h_{p-1} of the group's rows, this wave's K quarter.  Both chunks' loads are issued
+            // back to back; chunk 0 is verified and multiplied while chunk 1 is still landing.
             const bool c1 = rb + 16 < row_end;                       // second chunk present (uniform)
+            constexpr int NQ = (KS % 4 == 0) ? KS / 4 : 1;
+            u32x4 ra[2][NQ];
+            float as[2][KS];                                         // scalar path (small test dims only)
+            unsigned aoff[2] = {0, 0};
+            const bool have = !(ab & 1) && (p > 0 || J.h0 != nullptr);
+            const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (c == 1 && !c1) break;
                 const int row = min(rb + 16 * c + n, B - 1);         // clamped: rows >= B are never stored
-                unsigned aoff = 0; bool have = !(ab & 1);
-                if (p == 0) { have = have && J.h0 != nullptr; aoff = (unsigned)((size_t)row * D * 4); }
+                if (p == 0) aoff[c] = (unsigned)((size_t)row * D * 4);
                 else {
                     const int len = J.reverse ? (one_sc ? len_a[c] : a.lens[row]) : 0;
-                    aoff = (unsigned)((((size_t)pos_map(p - 1, len, J.reverse) * B + row) * a.ldh) * 4);
+                    aoff[c] = (unsigned)((((size_t)pos_map(p - 1, len, J.reverse) * B + row) * a.ldh) * 4);
                 }
-                if (!have) {
+                aoff[c] += (wave * WK + 4 * kh) * 4;
+                if constexpr (KS % 4 == 0) {
+                    if (have) frag_issue<NQ>(ra[c], rs, aoff[c]);
+                    else {
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) av[c][ks] = 0.f;
-                } else if constexpr (KS % 4 == 0) {
-                    load_frag<KS / 4>(av[c], (p == 0) ? rs_h0 : rs_hs, aoff + (wave * WK + 4 * kh) * 4, poll, a.err);
-                } else {
-                    load_frag_scalar<KS, KS>(av[c], ((p == 0) ? J.h0 : J.hs) + aoff / 4 + wave * WK, 0, kh, poll, a.err);
+                        for (int q = 0; q < NQ; ++q) ra[c][q] = (u32x4){0u, 0u, 0u, 0u};
+                    }
                 }
             }
             AVAE_STAMP(1);
-            // (3) MFMAs
+            // (3) verify + MFMAs, chunk by chunk
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (c == 1 && !c1) break;
+                if constexpr (KS % 4 == 0) {
+                    if (poll && have) frag_ensure<NQ>(ra[c], rs, aoff[c], a.err);
+                } else {
+                    if (have) load_frag_scalar<KS, KS>(as[c], ((p == 0) ? J.h0 : J.hs) + aoff[c] / 4 - 4 * kh, 0, kh, poll, a.err);
+                    else {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) as[c][ks] = 0.f;
+                    }
+                }
+                auto aval = [&](int ks) -> float {
+                    if constexpr (KS % 4 == 0) return __uint_as_float(ra[c][ks >> 2][ks & 3]);
+                    else return as[c][ks];
+                };
                 f32x4 acc[3];
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -289,25 +336,23 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                         for (int gate = 0; gate < 3; ++gate)
-                            acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][ks], w[gate][ks], acc[gate], 0, 0, 0);
+                            acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(aval(ks), w[gate][ks], acc[gate], 0, 0, 0);
                 }
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate)
                     *reinterpret_cast<f32x4*>(&part[buf][c][wave][gate][lane * 4]) = acc[gate];
                 // (4) own h_{p-1} slice -> LDS: lane (kh*16 + r) holds h[r][k = wave*WK + 16q + 4kh + e]
-                if (KS % 4 == 0) {
+                if constexpr (KS % 4 == 0) {
                     if (wave == own_wave) {
 #pragma unroll
-                        for (int q = 0; q < KS / 4; ++q)
-                            if (q == own_q)
-                                *reinterpret_cast<float4*>(&hps[buf][c][n][4 * kh]) =
-                                    make_float4(av[c][4 * q], av[c][4 * q + 1], av[c][4 * q + 2], av[c][4 * q + 3]);
+                        for (int q = 0; q < NQ; ++q)
+                            if (q == own_q) *reinterpret_cast<u32x4*>(&hps[buf][c][n][4 * kh]) = ra[c][q];
                     }
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         int k = wave * WK + kperm<KS>(ks, kh) - ht * 16;
-                        if (k >= 0 && k < 16) hps[buf][c][n][k] = av[c][ks];
+                        if (k >= 0 && k < 16) hps[buf][c][n][k] = as[c][ks];
                     }
                 }
             }
@@ -352,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
             AVAE_STAMP(6);
         }
     }
-    if ((ab & 32) && tid == 0 && a.stamps) {
+    if (STAMPS && tid == 0 && a.stamps) {
         for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, ph[i]);
         atomicAdd(a.stamps + 8, (unsigned long long)(a.p_end - a.p_begin));
         atomicAdd(a.stamps + 9, (unsigned long long)(fast ? 1 : 0));
@@ -367,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 // dgh is the exchanged buffer (sentinel-filled by the launcher).  The bias gradients (column sums
 // of dgi / dgh over all rows and steps) are accumulated in registers across the whole launch and
 // leave through one LDS reduction + 96 float atomics.
-template <int KS>
+template <int KS, bool STAMPS>
 __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 {
     constexpr int D = 16 * KS, HT = KS, NKS = 3 * KS;   // wave K range = 3D/4 = 12*KS floats
@@ -436,31 +481,31 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
             }
             AVAE_STAMP(0);
             const bool c1 = rb + 16 < row_end;
-            // (2)+(3) A operand = dgh_{p+1} rows (K = 3D, this wave's quarter) in pieces: two piece
-            // buffers in flight, the next piece's loads are issued before the MFMAs of the current one;
-            // a piece that still carries sentinels is re-loaded just before it is consumed.
+            // (2)+(3) A operand = dgh_{p+1} rows (K = 3D, this wave's quarter) streamed in pieces through a ring
+            // of NB register buffers: the loads of piece st+NB-1 are issued BEFORE piece st is verified, so
+            // NB-1 pieces are always in flight behind the MFMAs of the current one (counted waits on the fast
+            // path; a piece that still carries sentinels is re-loaded in place until complete).
             constexpr int NH = (NKS % 16 == 0) ? 4 : ((NKS % 8 == 0) ? 2 : 1);   // pieces per chunk
             constexpr int HK = NKS / NH;                                          // MFMA steps per piece
-            float hv[2][HK];
+            constexpr int PQ = (NKS % 4 == 0) ? HK / 4 : 1;                       // 16-byte loads per piece and lane
+            constexpr int NB = 3;
+            u32x4 hv[NB][PQ];
+            float hs_[HK];                                                        // scalar path (small test dims)
             auto piece_off = [&](int c, int hf) -> unsigned {
                 const int row = min(rb + 16 * c + n, B - 1);
                 const int len = J.reverse ? (one_sc ? len_a[c] : a.lens[row]) : 0;
                 const int pos1 = pos_map(p + 1, len, J.reverse);
                 return (unsigned)((((size_t)pos1 * B + row) * a.ldg + wave * 12 * KS + hf * 4 * HK) * 4);
             };
-            auto issue = [&](float* dst, int c, int hf) {          // one pass, no check
-                if constexpr (NKS % 4 == 0) load_frag<HK / 4>(dst, rs_dgh, piece_off(c, hf) + 16 * kh, false, a.err);
-                else load_frag_scalar<HK, NKS>(dst, J.dgh + piece_off(c, 0) / 4, hf * HK, kh, false, a.err);
-            };
-            auto has_sentinel = [&](const float* v) -> bool {
-                bool bad = false;
-#pragma unroll
-                for (int i = 0; i < HK; ++i) bad |= __float_as_uint(v[i]) == kSentinel;
-                return __any(bad);
-            };
             const bool do_mm = have_next && !(ab & 1);
             const int nstage = (c1 ? 2 : 1) * NH;                     // (chunk, piece) stages, uniform
-            if (do_mm) { issue(hv[0], 0, 0); if (nstage > 1) issue(hv[1], 1 / NH, 1 % NH); }
+            if constexpr (NKS % 4 == 0) {
+                if (do_mm) {
+#pragma unroll
+                    for (int s0 = 0; s0 < NB - 1; ++s0)
+                        if (s0 < nstage) frag_issue<PQ>(hv[s0], rs_dgh, piece_off(s0 / NH, s0 % NH) + 16 * kh);
+                }
+            }
             f32x4 acc[4];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -473,14 +518,20 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                             for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                         if (do_mm) {
-                            if (poll) {
-                                SpinGuard sg;
-                                while (has_sentinel(hv[st & 1]) && !sg.expired(a.err)) issue(hv[st & 1], c, hf);
-                            }
+                            if constexpr (NKS % 4 == 0) {
+                                if (st + NB - 1 < nstage)
+                                    frag_issue<PQ>(hv[(st + NB - 1) % NB], rs_dgh, piece_off((st + NB - 1) / NH, (st + NB - 1) % NH) + 16 * kh);
+                                if (poll) frag_ensure<PQ>(hv[st % NB], rs_dgh, piece_off(c, hf) + 16 * kh, a.err);
 #pragma unroll
-                            for (int ks = 0; ks < HK; ++ks)
-                                acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[st & 1][ks], w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
-                            if (st + 2 < nstage) issue(hv[st & 1], (st + 2) / NH, (st + 2) % NH);
+                                for (int ks = 0; ks < HK; ++ks)
+                                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][ks >> 2][ks & 3]),
+                                                                                       w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
+                            } else {
+                                load_frag_scalar<HK, NKS>(hs_, J.dgh + piece_off(c, 0) / 4, hf * HK, kh, poll, a.err);
+#pragma unroll
+                                for (int ks = 0; ks < HK; ++ks)
+                                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hs_[ks], w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
+                            }
                         }
                         if (hf == NH - 1) {
                             f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -529,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
             AVAE_STAMP(6);
         }
     }
-    if ((ab & 32) && tid == 0 && a.stamps) {
+    if (STAMPS && tid == 0 && a.stamps) {
         for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + 16 + i, ph[i]);
         atomicAdd(a.stamps + 16 + 8, (unsigned long long)(a.p_end - a.p_begin));
         atomicAdd(a.stamps + 16 + 9, (unsigned long long)(fast ? 1 : 0));
@@ -556,10 +607,15 @@ bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 51
 template <bool FWD>
 static hipError_t launch(hipStream_t st, const GruArgs& a, int grid)
 {
-#define AVAE_GRU_CASE(KSV)                                                                          \
-    case KSV:                                                                                       \
-        if (FWD) hipLaunchKernelGGL((gru_fwd_kernel<KSV>), dim3(grid), dim3(256), 0, st, a);        \
-        else     hipLaunchKernelGGL((gru_bwd_kernel<KSV>), dim3(grid), dim3(256), 0, st, a);        \
+#define AVAE_GRU_CASE(KSV)                                                                                   \
+    case KSV:                                                                                                \
+        if (a.ablate & 32) {                                                                                 \
+            if (FWD) hipLaunchKernelGGL((gru_fwd_kernel<KSV, true>), dim3(grid), dim3(256), 0, st, a);       \
+            else     hipLaunchKernelGGL((gru_bwd_kernel<KSV, true>), dim3(grid), dim3(256), 0, st, a);       \
+        } else {                                                                                             \
+            if (FWD) hipLaunchKernelGGL((gru_fwd_kernel<KSV, false>), dim3(grid), dim3(256), 0, st, a);      \
+            else     hipLaunchKernelGGL((gru_bwd_kernel<KSV, false>), dim3(grid), dim3(256), 0, st, a);      \
+        }                                                                                                    \
         break;
     switch (a.D / 16) {
         AVAE_GRU_CASE(1)
