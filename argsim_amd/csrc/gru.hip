@@ -25,6 +25,7 @@
 // placement-independent protocol; speed only).  Every spin is bounded; on time-out the error word
 // is set and every wait falls through, so the grid always drains.
 #include "kernels.h"
+#include <type_traits>
 
 namespace avae {
 
@@ -121,10 +122,10 @@ __device__ __forceinline__ void frag_issue(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_
 template <int NQ>
 __device__ __forceinline__ bool frag_bad(const u32x4 (&v)[NQ])
 {
-    bool bad = false;
+    unsigned mx = 0u;                     // the sentinel is the largest unsigned value: one running maximum
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) bad |= (v[q].x == kSentinel) | (v[q].y == kSentinel) | (v[q].z == kSentinel) | (v[q].w == kSentinel);
-    return __any(bad);
+    for (int q = 0; q < NQ; ++q) mx = max(max(mx, max(v[q].x, v[q].y)), max(v[q].z, v[q].w));
+    return __any(mx == kSentinel);
 }
 // verify `v`; on sentinels re-load it until complete (bounded)
 template <int NQ>
@@ -134,6 +135,31 @@ __device__ __forceinline__ void frag_ensure(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc
         SpinGuard sg;
         do { frag_issue<NQ>(v, rs, off); } while (frag_bad<NQ>(v) && !sg.expired(err));
     }
+}
+
+// Hand-counted form of the same pipeline for the D = 512 backward pass.  hipcc's waitcnt insertion falls
+// back to vmcnt(0) around the re-load branches of frag_ensure, which serialises every piece behind a
+// full L2 round trip; these loads are invisible to it (inline asm), are waited for by explicit counted
+// s_waitcnt statements that name the destination registers, and are fully retired before the code leaves
+// the block that issued them (cdna_hip_programming.md section 5.7 forms (ii)/(iii)).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void asm_issue6(u32x4 (&v)[6], unsigned voff, i32x4 srd)
+{
+    asm volatile("buffer_load_dwordx4 %0, %6, %7, 0 offen offset:%c8 sc1\n\t"
+                 "buffer_load_dwordx4 %1, %6, %7, 0 offen offset:%c9 sc1\n\t"
+                 "buffer_load_dwordx4 %2, %6, %7, 0 offen offset:%c10 sc1\n\t"
+                 "buffer_load_dwordx4 %3, %6, %7, 0 offen offset:%c11 sc1\n\t"
+                 "buffer_load_dwordx4 %4, %6, %7, 0 offen offset:%c12 sc1\n\t"
+                 "buffer_load_dwordx4 %5, %6, %7, 0 offen offset:%c13 sc1"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                 : "v"(voff), "s"(srd), "i"(OFF), "i"(OFF + 64), "i"(OFF + 128), "i"(OFF + 192), "i"(OFF + 256), "i"(OFF + 320)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait6(u32x4 (&v)[6])
+{
+    asm volatile("s_waitcnt vmcnt(%c6)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : "i"(N) : "memory");
 }
 
 // scalar-element variant for the small test dimensions (wave K range not a multiple of 16)
@@ -499,6 +525,75 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
             };
             const bool do_mm = have_next && !(ab & 1);
             const int nstage = (c1 ? 2 : 1) * NH;                     // (chunk, piece) stages, uniform
+            f32x4 acc[4];
+            // D = 512 fast form.  (a) A one-instruction probe -- lane l reads the last element producer l&31
+            // stores for chunk l>>5 -- is polled until no sentinel is left: a HEURISTIC start signal (the stores
+            // of one producer are unordered).  (b) The whole A operand then streams through the register ring
+            // in straight-line code with hand-counted waits, so two pieces stay in flight behind the MFMAs of
+            // the current one, while every loaded dword is also compared with the sentinel.  (c) If any lane of
+            // the wave saw one, the partial sums are discarded and the pass repeats (bounded).  Correctness
+            // rests on (b)+(c) only.
+            if constexpr (KS == 32) {
+                if (!do_mm) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        if (c == 0 || c1) *reinterpret_cast<f32x4*>(&part[buf][c][wave][lane * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const unsigned long long pa = (unsigned long long)J.dgh;
+                    const i32x4 srd = {(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
+                    const unsigned voff0 = piece_off(0, 0) + 16 * kh, voff1 = c1 ? piece_off(1, 0) + 16 * kh : voff0;
+                    auto pass = [&](auto nst_tag) __attribute__((always_inline)) -> bool {
+                        constexpr int NST = decltype(nst_tag)::value;       // 4 (one chunk) or 8 (two chunks)
+                        unsigned mx = 0u;
+                        asm_issue6<0>(hv[0], voff0, srd);
+                        asm_issue6<384>(hv[1], voff0, srd);
+#pragma unroll
+                        for (int st = 0; st < NST; ++st) {
+                            const int c = st / NH, hf = st % NH;
+                            if (st + 2 < NST) {
+                                const unsigned vo = ((st + 2) / NH) ? voff1 : voff0;
+                                if ((st + 2) % NH == 0) asm_issue6<0>(hv[(st + 2) % NB], vo, srd);
+                                if ((st + 2) % NH == 1) asm_issue6<384>(hv[(st + 2) % NB], vo, srd);
+                                if ((st + 2) % NH == 2) asm_issue6<768>(hv[(st + 2) % NB], vo, srd);
+                                if ((st + 2) % NH == 3) asm_issue6<1152>(hv[(st + 2) % NB], vo, srd);
+                            }
+                            if (st + 2 < NST) asm_wait6<12>(hv[st % NB]);
+                            else if (st + 1 < NST) asm_wait6<6>(hv[st % NB]);
+                            else asm_wait6<0>(hv[st % NB]);
+                            if (hf == 0) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            // sentinel = the largest unsigned value: keep a running maximum of every loaded dword
+                            // (pinned here so that the ring registers die before their buffer is re-loaded)
+#pragma unroll
+                            for (int q = 0; q < PQ; ++q)
+                                mx = max(max(mx, max(hv[st % NB][q].x, hv[st % NB][q].y)), max(hv[st % NB][q].z, hv[st % NB][q].w));
+                            asm volatile("" : "+v"(mx));
+#pragma unroll
+                            for (int ks = 0; ks < HK; ++ks)
+                                acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][ks >> 2][ks & 3]),
+                                                                                   w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
+                            if (hf == NH - 1) {
+                                f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                                *reinterpret_cast<f32x4*>(&part[buf][c][wave][lane * 4]) = s;
+                            }
+                        }
+                        return __any(mx == kSentinel);
+                    };
+                    SpinGuard sg;
+                    for (;;) {
+                        if (poll) {
+                            const int pc = c1 ? (lane >> 5) : 0, prow = min(min(rb + 16 * pc + 15, row_end - 1), B - 1);
+                            const int plen = J.reverse ? a.lens[prow] : 0;
+                            const float* pp = J.dgh + ((size_t)pos_map(p + 1, plen, J.reverse) * B + prow) * a.ldg + (lane & 31) * 48 + 47;
+                            while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                        }
+                        const bool bad = c1 ? pass(std::integral_constant<int, 2 * NH>{}) : pass(std::integral_constant<int, NH>{});
+                        if (!poll || !bad || sg.expired(a.err)) break;
+                    }
+                }
+            } else {
             if constexpr (NKS % 4 == 0) {
                 if (do_mm) {
 #pragma unroll
@@ -506,7 +601,6 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                         if (s0 < nstage) frag_issue<PQ>(hv[s0], rs_dgh, piece_off(s0 / NH, s0 % NH) + 16 * kh);
                 }
             }
-            f32x4 acc[4];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -540,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                     }
                 }
             }
+            }   // KS != 32: compiler-tracked form
             AVAE_STAMP(2);
             __syncthreads();
             AVAE_STAMP(3);
