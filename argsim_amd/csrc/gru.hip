@@ -431,6 +431,177 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ forward, D = 512, 32 rows per group
+// Software-pipelined form of the same algorithm for the benchmark geometry (two full 16-row chunks per
+// workgroup).  Work item = (step, chunk).  The A-operand loads of item i+1 are issued (inline asm, hand
+// counted) right after item i's own fragment has been verified, and land while item i runs its MFMAs, LDS
+// reduction and gate math: chunk 1 of a step only needs step p-1 data, and chunk 0 of step p+1 needs what every
+// workgroup stored one whole item earlier, so the exchange latency leaves the critical path.  A fragment that
+// still carries a sentinel is re-loaded in place until complete (same protocol, same bounds).
+template <int OFF>
+__device__ __forceinline__ void asm_issue8(u32x4 (&v)[8], unsigned voff, i32x4 srd)
+{
+    asm volatile("buffer_load_dwordx4 %0, %8, %9, 0 offen offset:%c10 sc1\n\t"
+                 "buffer_load_dwordx4 %1, %8, %9, 0 offen offset:%c11 sc1\n\t"
+                 "buffer_load_dwordx4 %2, %8, %9, 0 offen offset:%c12 sc1\n\t"
+                 "buffer_load_dwordx4 %3, %8, %9, 0 offen offset:%c13 sc1\n\t"
+                 "buffer_load_dwordx4 %4, %8, %9, 0 offen offset:%c14 sc1\n\t"
+                 "buffer_load_dwordx4 %5, %8, %9, 0 offen offset:%c15 sc1\n\t"
+                 "buffer_load_dwordx4 %6, %8, %9, 0 offen offset:%c16 sc1\n\t"
+                 "buffer_load_dwordx4 %7, %8, %9, 0 offen offset:%c17 sc1"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(voff), "s"(srd), "i"(OFF), "i"(OFF + 64), "i"(OFF + 128), "i"(OFF + 192), "i"(OFF + 256), "i"(OFF + 320),
+                   "i"(OFF + 384), "i"(OFF + 448)
+                 : "memory");
+}
+__device__ __forceinline__ void asm_wait8_all(u32x4 (&v)[8])
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+}
+__device__ __forceinline__ i32x4 make_srd(const float* p)
+{
+    const unsigned long long pa = (unsigned long long)p;
+    return (i32x4){(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
+}
+
+__global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
+{
+    constexpr int KS = 32, D = 512, HT = 32, WK = 128;
+    __shared__ __attribute__((aligned(16))) float part[2][4][3][256];   // [item parity][wave][gate][lane*4+reg]
+    __shared__ __attribute__((aligned(16))) float hps[2][16][16];       // [item parity][row][unit] own h_{p-1} slice
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kh = lane >> 4;
+    int jb, g, ht;
+    const bool second_half = wg_map(a, HT, &jb, &g, &ht);
+    const GruJob& J = a.job[jb];
+    const int B = a.B;
+    const int row_beg = g * 32;
+
+    float w[3][KS];
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) {
+        const float* rp = J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wave * WK;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            float4 v = *reinterpret_cast<const float4*>(rp + 16 * q + 4 * kh);
+            w[gate][4 * q + 0] = v.x; w[gate][4 * q + 1] = v.y; w[gate][4 * q + 2] = v.z; w[gate][4 * q + 3] = v.w;
+        }
+    }
+    const int gn = tid & 15, gr = tid >> 4;
+    const int j = ht * 16 + gn;
+    float bR[3];
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
+    const int own_wave = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
+    int len_a[2] = {0, 0}, len_g[2] = {0, 0};
+    if (J.reverse) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { len_a[c] = a.lens[row_beg + 16 * c + n]; len_g[c] = a.lens[row_beg + 16 * c + gr]; }
+    }
+    const i32x4 srd_hs = make_srd(J.hs), srd_h0 = make_srd(J.h0 ? J.h0 : J.hs);
+    const bool fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
+    if (second_half && a.stagger > 0) __builtin_amdgcn_s_sleep(127);
+
+    const int total = 2 * (a.p_end - a.p_begin);
+    // byte offset of this lane's first 16-byte piece of the A fragment of item `it`; have == false: zeros
+    auto item_off = [&](int it, bool* have, bool* from_h0) -> unsigned {
+        const int p = a.p_begin + (it >> 1), c = it & 1;
+        const int row = row_beg + 16 * c + n;
+        *from_h0 = p == 0;
+        *have = p > 0 || J.h0 != nullptr;
+        if (p == 0) return (unsigned)((size_t)row * D * 4) + (wave * WK + 4 * kh) * 4;
+        return (unsigned)((((size_t)pos_map(p - 1, len_a[c], J.reverse) * B + row) * a.ldh) * 4) + (wave * WK + 4 * kh) * 4;
+    };
+    u32x4 ra[2][8];
+    {
+        bool have, h0;
+        const unsigned off = item_off(0, &have, &h0);
+        if (have) asm_issue8<0>(ra[0], off, h0 ? srd_h0 : srd_hs);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ra[0][q] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+    auto item = [&](int p, auto c_tag) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_tag)::value, buf = c;              // two items per step: parity == chunk
+        const int it = 2 * (p - a.p_begin) + c;
+        u32x4 (&cur)[8] = ra[c];
+        // (1) this item's fragment: everything issued so far must have landed; verify, re-load if needed
+        {
+            bool have, h0;
+            const unsigned off = item_off(it, &have, &h0);
+            if (have) {
+                asm_wait8_all(cur);
+                if (p > a.p_begin) {
+                    SpinGuard sg;
+                    for (;;) {
+                        unsigned mx = 0u;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) mx = max(max(mx, max(cur[q].x, cur[q].y)), max(cur[q].z, cur[q].w));
+                        if (!__any(mx == kSentinel) || sg.expired(a.err)) break;
+                        asm_issue8<0>(cur, off, srd_hs);
+                        asm_wait8_all(cur);
+                    }
+                }
+            }
+        }
+        // (2) the next item's fragment goes in flight now
+        if (it + 1 < total) {
+            bool have, h0;
+            const unsigned off = item_off(it + 1, &have, &h0);
+            if (have) asm_issue8<0>(ra[c ^ 1], off, h0 ? srd_h0 : srd_hs);
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ra[c ^ 1][q] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+        // (3) exchange-independent loads of the gate phase (land behind the MFMAs)
+        const int grow = row_beg + 16 * c + gr;
+        const int gpos = pos_map(p, len_g[c], J.reverse);
+        const float* gp = J.gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
+        const float gi0 = gp[0], gi1 = gp[1], gi2 = gp[2];
+        // (4) MFMAs
+        f32x4 acc[3];
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(cur[ks >> 2][ks & 3]), w[gate][ks], acc[gate], 0, 0, 0);
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+            *reinterpret_cast<f32x4*>(&part[buf][wave][gate][lane * 4]) = acc[gate];
+        if (wave == own_wave) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q == own_q) *reinterpret_cast<u32x4*>(&hps[buf][n][4 * kh]) = cur[q];
+        }
+        __syncthreads();
+        // (5) gate math: 16 rows x 16 units, one element per thread; exchanged store first
+        {
+            const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
+            float gh[3];
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                gh[gate] = bR[gate] + ((part[buf][0][gate][pidx] + part[buf][1][gate][pidx]) + (part[buf][2][gate][pidx] + part[buf][3][gate][pidx]));
+            const float hprev = hps[buf][gr][gn];
+            const float r = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r * gh[2]);
+            const float hnew = (1.f - u) * nn + u * hprev;
+            const size_t rix = (size_t)gpos * B + grow;
+            float* hdst = J.hs + rix * a.ldh + j;
+            if (fast) *hdst = hnew; else store4_sc1(hdst, hnew);
+            if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r, u, nn, gh[2]);
+            if (J.hp) J.hp[rix * D + j] = hprev;
+        }
+    };
+    for (int p = a.p_begin; p < a.p_end; ++p) {
+        item(p, std::integral_constant<int, 0>{});
+        item(p, std::integral_constant<int, 1>{});
+    }
+}
+
 // ------------------------------------------------------------------------------ backward
 // step p (descending):  dH_p = dh_out[p] + dH_{p+1} u_{p+1} + dgh_{p+1} R'
 //   dn = dH (1-u)(1-n^2)   du = dH (h_{p-1} - n) u (1-u)   dr = dn hn r (1-r)
@@ -772,6 +943,11 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
         e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
+        // benchmark geometry (D = 512, two full 16-row chunks per workgroup): software-pipelined kernel
+        if (a.D == 512 && a.rows_per_group == 32 && a.B % 32 == 0 && a.G * 32 == a.B && !a.ablate && a.item_pipeline) {
+            hipLaunchKernelGGL(gru_fwd_item_kernel, dim3(grid), dim3(256), 0, st, a);
+            return hipGetLastError();
+        }
         return launch<true>(st, a, grid);
     }
     for (int p = a.p_begin; p < a.p_end; ++p) {
