@@ -210,16 +210,22 @@ __device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, in
 // staggered by part of a step.  Any placement is correct; this is speed only.
 __device__ __forceinline__ bool wg_map(const GruArgs& a, int HT, int* jb, int* g, int* ht)
 {
-    const int per_job = a.G * HT, total = a.njobs * per_job, bid = blockIdx.x;
-    if (a.njobs == 1 && (a.G & 1) == 0 && a.G >= 2) {
-        const int halfn = total / 2, half = bid / halfn, r = bid - half * halfn, gh = a.G / 2;
-        *jb = 0; *g = (r % gh) + gh * half; *ht = r / gh;
-        return half != 0;
+    const int per_job = a.G * HT, bid = blockIdx.x;
+    // alt = which of two interleaved sets a block belongs to: blocks b and b+8 (consecutive blocks of one
+    // XCD, which the dispatcher was observed to place on the same CU) get different chains
+    const int alt = (bid >> 3) & 1, idx = ((bid >> 4) << 3) | (bid & 7);
+    if (a.njobs == 2 && (per_job & 7) == 0) {                       // the two encoder directions
+        *jb = alt; *g = idx % a.G; *ht = idx / a.G;
+        return alt != 0;
+    }
+    if (a.njobs == 1 && a.G == 16) {                                // one decoder layer: groups g and g+8
+        *jb = 0; *g = (bid & 7) + 8 * alt; *ht = bid >> 4;
+        return alt != 0;
     }
     *jb = bid / per_job;
     const int rem = bid - *jb * per_job;
     *g = rem % a.G; *ht = rem / a.G;
-    return a.njobs == 2 && *jb == 1;
+    return false;
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     bool fast = false;
     if (a.p_end - a.p_begin > 1 && !(ab & 16))
         fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
-    if (second_half && a.p_end - a.p_begin > 1 && a.stagger > 0) __builtin_amdgcn_s_sleep(127);   // ~half a step
+    if (second_half && a.p_end - a.p_begin > 1) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);   // stagger x ~1 us
     int buf = 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_begin; p < a.p_end; ++p) {
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
     }
     const i32x4 srd_hs = make_srd(J.hs), srd_h0 = make_srd(J.h0 ? J.h0 : J.hs);
     const bool fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
-    if (second_half && a.stagger > 0) __builtin_amdgcn_s_sleep(127);
+    if (second_half) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);   // stagger x ~1 us
 
     const int total = 2 * (a.p_end - a.p_begin);
     // byte offset of this lane's first 16-byte piece of the A fragment of item `it`; have == false: zeros
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     bool fast = false;
     if (a.p_end - 1 > p_last && !(ab & 16))
         fast = group_same_xcd(a.counters + 64 + jb * a.G + g, a.counters + 128 + (jb * a.G + g) * HT, ht, HT, a.err, a.force_slow);
-    if (second_half && a.p_end - 1 > p_last && a.stagger > 0) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(64); }
+    if (second_half && a.p_end - 1 > p_last) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);   // stagger x ~1 us
     int buf = 0, done = 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
