@@ -608,6 +608,154 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ forward, D = 512, four teams per CU
+// The register-resident form above tops out at two chains per CU (96 weight registers per lane allow only
+// 2 waves per SIMD) and the matrix pipe sits ~50 % idle while those two chains wait on their exchange.
+// Here ONE workgroup of 16 waves owns a (job, 16-unit slice) pair: its 48 x 512 weight slice lives in LDS
+// (96 KB, already in MFMA B-fragment order, one ds_read_b128 per gate and four MFMA steps) and is shared by
+// FOUR teams of 4 waves; every team runs an independent 16-row chain (its own A fragment, K split over its 4
+// waves, partial sums and gate math inside the team).  4 waves per SIMD = four chains to fill the matrix
+// pipe.  Teams synchronise through two monotonic LDS counters per team (LDS atomics + LDS polling; never
+// s_barrier, which would put the four chains in lock step).  Exchange between workgroups: the same in-band
+// sentinel protocol as above.
+constexpr int kTeams = 4;
+struct TeamSync { unsigned arrive[kTeams]; };
+
+__device__ __forceinline__ void team_barrier(unsigned* word, unsigned target)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's LDS traffic is done
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
+{
+    constexpr int D = 512, HT = 32, WK = 128;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wl = lds;                                        // [wk 4][gate 3][q 8][lane 64][4]   96 KB
+    float* part = Wl + 4 * 3 * 8 * 256;                     // [team 4][wk 4][gate 3][256]        48 KB
+    float* hps = part + kTeams * 4 * 3 * 256;               // [team 4][16][16]                    4 KB
+    unsigned* sync = reinterpret_cast<unsigned*>(hps + kTeams * 256);      // [team 4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = wave >> 2, wk = wave & 3;
+    const int n = lane & 15, kh = lane >> 4;
+    // blockIdx -> (row block of 64, job) on the XCD axis, hidden tile on the other: the 32 workgroups that
+    // exchange with each other share blockIdx % 8 (one XCD under round-robin dispatch; speed only)
+    const int nrb = a.B / 64;                               // row blocks per job
+    const int chains = a.njobs * nrb;                       // (job, row block) pairs, <= 8
+    const int cid = blockIdx.x % chains, ht = blockIdx.x / chains;
+    const int jb = cid / nrb, rblk = cid % nrb;
+    const GruJob& J = a.job[jb];
+    const int B = a.B;
+    const int row0 = rblk * 64 + team * 16;                 // this team's 16 rows
+
+    // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
+    for (int blk = wave; blk < 96; blk += 16) {
+        const int wq = blk / 24, gate = (blk / 8) % 3, q = blk & 7;
+        const float4 v = *reinterpret_cast<const float4*>(J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 16 * q + 4 * kh);
+        *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = v;
+    }
+    if (tid < kTeams) sync[tid] = 0u;
+    const int tt = tid & 255;                               // thread inside the team
+    const int gn = tt & 15, gr = tt >> 4;
+    const int j = ht * 16 + gn;
+    float bR[3];
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
+    const int own_wk = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
+    const int len_a = J.reverse ? a.lens[row0 + n] : 0, len_g = J.reverse ? a.lens[row0 + gr] : 0;
+    const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
+    const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
+    float* tpart = part + team * (4 * 3 * 256);
+    float* thps = hps + team * 256;
+    unsigned* tsync = sync + team;
+    unsigned epoch = 0;
+    // de-phase the four chains: identical chains started together stay in lock step and collide on the matrix
+    // pipe; an initial offset of a fraction of a step per team persists (equal periods)
+    for (int i = 0; i < team * a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+
+    for (int p = a.p_begin; p < a.p_end; ++p) {
+        const bool poll = p > a.p_begin;
+        // (1) exchange-independent loads of the gate phase
+        const int grow = row0 + gr;
+        const int gpos = pos_map(p, len_g, J.reverse);
+        const float* gp = J.gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
+        const float gi0 = gp[0], gi1 = gp[1], gi2 = gp[2];
+        // (2) A operand: this wave's K quarter of the team's 16 rows
+        u32x4 ra[8];
+        const bool have = p > 0 || J.h0 != nullptr;
+        if (have) {
+            const int row = row0 + n;
+            unsigned aoff = (p == 0) ? (unsigned)((size_t)row * D * 4)
+                                     : (unsigned)((((size_t)pos_map(p - 1, len_a, J.reverse) * B + row) * a.ldh) * 4);
+            aoff += (wk * WK + 4 * kh) * 4;
+            const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
+            if (poll) {
+                // cheap start signal: lane l reads the last element producer l&31 stores for these 16 rows (one
+                // 256-byte request per poll instead of re-reading the 8 KB fragment: 128 waves poll the same
+                // lines); the fragment itself is still verified dword by dword below
+                const int prow = row0 + 15;
+                const int plen = J.reverse ? a.lens[prow] : 0;
+                const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
+                SpinGuard sg;
+                while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+            }
+            frag_issue<8>(ra, rs, aoff);
+            if (poll) frag_ensure<8>(ra, rs, aoff, a.err);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        // (3) MFMAs, B fragments from LDS
+        f32x4 acc[3];
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f32x4 b[3];
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                b[gate] = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 3 + gate) * 8 + q) * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)            // gates interleaved: consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int gate = 0; gate < 3; ++gate)
+                    acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ra[q][e]), b[gate][e], acc[gate], 0, 0, 0);
+        }
+        // every wave of the team has finished READING the previous step's partial sums (second team barrier
+        // of that step, taken here so that it costs nothing), then publish this step's
+        if (p > a.p_begin) { epoch += 4; team_barrier(tsync, epoch); }
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+            *reinterpret_cast<f32x4*>(tpart + (wk * 3 + gate) * 256 + lane * 4) = acc[gate];
+        if (wk == own_wk) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q == own_q) *reinterpret_cast<u32x4*>(thps + n * 16 + 4 * kh) = ra[q];
+        }
+        epoch += 4; team_barrier(tsync, epoch);
+        // (4) gate math: the team's 256 threads, one element each; exchanged store first
+        {
+            const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
+            float gh[3];
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                gh[gate] = bR[gate] + ((tpart[(0 * 3 + gate) * 256 + pidx] + tpart[(1 * 3 + gate) * 256 + pidx]) +
+                                       (tpart[(2 * 3 + gate) * 256 + pidx] + tpart[(3 * 3 + gate) * 256 + pidx]));
+            const float hprev = thps[gr * 16 + gn];
+            const float r = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r * gh[2]);
+            const float hnew = (1.f - u) * nn + u * hprev;
+            const size_t rix = (size_t)gpos * B + grow;
+            float* hdst = J.hs + rix * a.ldh + j;
+            if (fast) *hdst = hnew; else store4_sc1(hdst, hnew);
+            if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r, u, nn, gh[2]);
+            if (J.hp) J.hp[rix * D + j] = hprev;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ backward
 // step p (descending):  dH_p = dh_out[p] + dH_{p+1} u_{p+1} + dgh_{p+1} R'
 //   dn = dH (1-u)(1-n^2)   du = dH (h_{p-1} - n) u (1-u)   dr = dn hn r (1-r)
@@ -949,6 +1097,18 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
         e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
+        // D = 512, two directions, B = 64 x (1..4): four independent 16-row teams per CU, weights in LDS
+        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !a.ablate && a.item_pipeline == 2) {
+            const int lds_bytes = (4 * 3 * 8 * 256 + kTeams * 4 * 3 * 256 + kTeams * 256) * 4 + 64;
+            static bool attr_set = false;
+            if (!attr_set) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gru_fwd_team_kernel, dim3(a.njobs * (a.B / 64) * 32), dim3(1024), lds_bytes, st, a);
+            return hipGetLastError();
+        }
         // benchmark geometry (D = 512, two full 16-row chunks per workgroup): software-pipelined kernel
         if (a.D == 512 && a.rows_per_group == 32 && a.B % 32 == 0 && a.G * 32 == a.B && !a.ablate && a.item_pipeline) {
             hipLaunchKernelGGL(gru_fwd_item_kernel, dim3(grid), dim3(256), 0, st, a);

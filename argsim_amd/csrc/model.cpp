@@ -46,7 +46,7 @@ struct avae_ctx {
     int64_t step = 0;
     avae_grad_hook hook = nullptr; void* hook_user = nullptr;
     int persistent = 1;
-    int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 1, gru_item = 1;
+    int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
     std::vector<GruP> enc;     // per layer: W = [fwd;bwd] (6D,In), R = [fwd;bwd], bW (6D), bR (6D)

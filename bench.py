@@ -79,7 +79,8 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'),
                     help="f32 = the reference's precision (headline); bf16 = bf16 GEMM operands, fp32 everything else")
     ap.add_argument('--no-timing', action='store_true', help="skip the per-kernel HIP-event stamps (roofline leg)")
-    ap.add_argument('--gru-stagger', type=int, default=1)
+    ap.add_argument('--gru-stagger', type=int, default=0)
+    ap.add_argument('--gru-item', type=int, default=-1, help="forward GRU kernel: 0 generic, 1 item pipeline, 2 four-team LDS-weight kernel")
     ap.add_argument('--gru-force-slow', action='store_true', help="never use the same-XCD L2 exchange path")
     ap.add_argument('--gru-ablate', type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument('--stepwise', action='store_true', help="one GRU launch per time step instead of the persistent kernels")
@@ -108,6 +109,8 @@ def main():
     if A.stepwise:
         model.set_option('persistent', 0)
     model.set_option('gru_stagger', A.gru_stagger)
+    if A.gru_item >= 0:
+        model.set_option('gru_item', A.gru_item)
     if A.gru_force_slow:
         model.set_option('gru_force_slow', 1)
     if A.gru_ablate:

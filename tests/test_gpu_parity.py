@@ -210,6 +210,15 @@ def test_bench_scale_persistent_equals_stepwise():
     m = VAE('train', seed=3, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
     ids = synth.batch(256, 64, 8192, ragged=True, seed=5)
     m.step = 20000
+    # every forward-kernel variant (0 generic, 1 item pipeline, 2 four-team LDS-weight kernel) must reproduce
+    # the one-launch-per-step encoder bit for bit
+    m.set_option('persistent', 0)
+    z_ref = m.encode(ids)
+    m.set_option('persistent', 1)
+    for item in (0, 1, 2):
+        m.set_option('gru_item', item)
+        assert np.array_equal(m.encode(ids), z_ref), item
+    m.set_option('gru_item', 2)
     res = {}
     for mode in (1, 0, 1):
         m.set_option('persistent', mode)
