@@ -657,7 +657,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         const float4 v = *reinterpret_cast<const float4*>(J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 16 * q + 4 * kh);
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = v;
     }
-    if (tid < kTeams) sync[tid] = 0u;
+    if (tid < 2 * kTeams) sync[tid] = 0u;                   // [0..3] team barrier counters, [4..7] exchange-ready epochs
     const int tt = tid & 255;                               // thread inside the team
     const int gn = tt & 15, gr = tt >> 4;
     const int j = ht * 16 + gn;
@@ -675,9 +675,22 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     // de-phase the four chains: identical chains started together stay in lock step and collide on the matrix
     // pipe; an initial offset of a fraction of a step per team persists (equal periods)
     for (int i = 0; i < team * a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    // one consistent arbitration order on all four SIMDs: a team's K-split partners sit on different SIMDs and
+    // meet at the team barrier, so if every SIMD serves the teams in the same order the partners finish together
+    // (otherwise the barrier pays the arbitration skew, measured at 2-3 us per step)
+    if (a.ablate & 256) { } else {
+        const int tq = __builtin_amdgcn_readfirstlane(team);
+        if (tq == 0) __builtin_amdgcn_s_setprio(3);
+        else if (tq == 1) __builtin_amdgcn_s_setprio(2);
+        else if (tq == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
+    const bool stamp = (a.ablate & 128) != 0;                  // diagnostic phase stamps (never in timed runs)
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+#define TSTAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
     for (int p = a.p_begin; p < a.p_end; ++p) {
-        const bool poll = p > a.p_begin;
+        TSTAMP(5);
+        const bool poll = p > a.p_begin && !(a.ablate & 16);      // ablate 16: timing experiment, wrong results
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
@@ -693,14 +706,22 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             aoff += (wk * WK + 4 * kh) * 4;
             const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
             if (poll) {
-                // cheap start signal: lane l reads the last element producer l&31 stores for these 16 rows (one
-                // 256-byte request per poll instead of re-reading the 8 KB fragment: 128 waves poll the same
-                // lines); the fragment itself is still verified dword by dword below
-                const int prow = row0 + 15;
-                const int plen = J.reverse ? a.lens[prow] : 0;
-                const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
-                SpinGuard sg;
-                while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                // ONE wave per team polls the exchange and releases its three K-split partners through an LDS
+                // word: four independent polls would leave the partners up to a poll period (~1 us) apart and
+                // the team barrier pays that skew.  The probe (lane l reads the last element producer l&31
+                // stores for these 16 rows: one 256-byte request per poll) is a start signal only; every wave
+                // still verifies its own fragment dword by dword below.
+                unsigned* ready = sync + kTeams + team;
+                if (wk == 0) {
+                    const int prow = row0 + 15;
+                    const int plen = J.reverse ? a.lens[prow] : 0;
+                    const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
+                    SpinGuard sg;
+                    while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                    if (lane == 0) __hip_atomic_store(ready, (unsigned)(p - a.p_begin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(p - a.p_begin)) __builtin_amdgcn_s_sleep(1);
+                }
             }
             frag_issue<8>(ra, rs, aoff);
             if (poll) frag_ensure<8>(ra, rs, aoff, a.err);
@@ -708,6 +729,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 #pragma unroll
             for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
+        TSTAMP(0);
         // (3) MFMAs, B fragments from LDS
         f32x4 acc[3];
 #pragma unroll
@@ -724,6 +746,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 for (int gate = 0; gate < 3; ++gate)
                     acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ra[q][e]), b[gate][e], acc[gate], 0, 0, 0);
         }
+        TSTAMP(1);
         // every wave of the team has finished READING the previous step's partial sums (second team barrier
         // of that step, taken here so that it costs nothing), then publish this step's
         if (p > a.p_begin) { epoch += 4; team_barrier(tsync, epoch); }
@@ -736,6 +759,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 if (q == own_q) *reinterpret_cast<u32x4*>(thps + n * 16 + 4 * kh) = ra[q];
         }
         epoch += 4; team_barrier(tsync, epoch);
+        TSTAMP(2);
         // (4) gate math: the team's 256 threads, one element each; exchanged store first
         {
             const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
@@ -753,7 +777,14 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r, u, nn, gh[2]);
             if (J.hp) J.hp[rix * D + j] = hprev;
         }
+        TSTAMP(3);
     }
+    if (stamp && (tid & 255) == 0 && a.stamps) {
+        for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, ph[i]);
+        atomicAdd(a.stamps + 8, (unsigned long long)(a.p_end - a.p_begin));
+        atomicAdd(a.stamps + 10, 1ULL);
+    }
+#undef TSTAMP
 }
 
 // ------------------------------------------------------------------------------ backward
@@ -1098,7 +1129,7 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     if (persistent && a.p_end - a.p_begin > 1) {
         e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
         // D = 512, two directions, B = 64 x (1..4): four independent 16-row teams per CU, weights in LDS
-        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !a.ablate && a.item_pipeline == 2) {
+        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !(a.ablate & ~(16 | 128 | 256)) && a.item_pipeline == 2) {
             const int lds_bytes = (4 * 3 * 8 * 256 + kTeams * 4 * 3 * 256 + kTeams * 256) * 4 + 64;
             static bool attr_set = false;
             if (!attr_set) {

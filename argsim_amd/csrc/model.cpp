@@ -215,7 +215,10 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
         AV_CHECK(gemm_bf16_nt(h->stream, h->bfA, Kp, h->bfB, Kp, g));
         return 0;
     }
-    AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
+    // compute_dtype 2: fp32 operands split into 3 x bf16 on the fly (6 partial products, fp32-accurate); thin
+    // row panels (a few rows, little work) stay on the exact-fp32 kernel's 32x128 tiles
+    if (h->cfg.compute_dtype == 2 && !thin) AV_CHECK(gemm_f32s(h->stream, a_mc, b_nc, g));
+    else AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
     return 0;
 }
 
@@ -597,7 +600,7 @@ int avae_create(const avae_config* cfg, int device, avae_handle* out)
     if (!cfg || !out) { g_create_err = "null argument"; return 1; }
     *out = nullptr;
     if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 64, 256, 512"; return 1; }
-    if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { g_create_err = "compute_dtype must be 0 (fp32) or 1 (bf16 GEMM operands)"; return 1; }
+    if (cfg->compute_dtype < 0 || cfg->compute_dtype > 2) { g_create_err = "compute_dtype must be 0 (fp32 MFMA), 1 (bf16 GEMM operands) or 2 (fp32 via split bf16 MFMA)"; return 1; }
     if (cfg->dim_rep % 4 || cfg->dim_tgt % 4 || cfg->rnn_layers < 1 || cfg->rnn_layers > 8) { g_create_err = "dim_rep and dim_tgt must be multiples of 4; 1 <= rnn_layers <= 8"; return 1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available: the gfx950 kernels cannot run (no CPU fallback)"; return 1; }

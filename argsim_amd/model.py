@@ -46,10 +46,11 @@ class VAE:
                         accelerate=accelerate, learn_rate=learn_rate, bos=bos, eos=eos)
         self._l = _lib.load()
         self.device = torch.device('cuda', device)
-        assert dtype in ('f32', 'bf16'), "dtype: 'f32' (exact, reference) or 'bf16' (bf16 GEMM operands, fp32 everything else)"
+        assert dtype in ('f32', 'bf16', 'f32s'), \
+            "dtype: 'f32' (fp32 MFMA, reference), 'f32s' (fp32 via split bf16 MFMA, fp32-accurate) or 'bf16' (bf16 GEMM operands)"
         self.dtype = dtype
         c = _lib.AvaeConfig(dim_tgt, dim_emb, dim_rep, rnn_layers, accelerate, learn_rate, bos, eos, 0, 0, kl_beta, free_bits,
-                            1 if dtype == 'bf16' else 0)
+                            {'f32': 0, 'bf16': 1, 'f32s': 2}[dtype])
         h = C.c_void_p()
         if self._l.avae_create(C.byref(c), device, C.byref(h)):
             raise RuntimeError("avae_create: " + self._l.avae_last_error(None).decode())

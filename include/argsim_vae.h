@@ -47,6 +47,8 @@ typedef struct avae_config {
     float   free_bits;    /* per-dimension KL floor (nats)     */
     int32_t compute_dtype;/* 0 = exact fp32 (reference);       */
                           /* 1 = bf16 GEMM operands, fp32 accumulate/state/weights (BASELINE configs[2]) */
+                          /* 2 = fp32 GEMMs on the bf16 matrix cores: each operand element split into 3 bf16 */
+                          /*     in registers, 6 partial products, fp32 accumulate (fp32-accurate)          */
 } avae_config;
 
 /* kind selector for avae_get_tensor / avae_set_tensor */

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from argsim_amd import lib
 l = lib.load()
-cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 0)
+cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, int(os.environ.get('DTYPE', '0')))   # 0 fp32 MFMA, 1 bf16, 2 split bf16x3
 h = C.c_void_p(); assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
 dev = torch.device('cuda', 0)
 shapes = [  # name, a_mc, b_nc, M, N, K, split
@@ -22,6 +22,7 @@ shapes = [  # name, a_mc, b_nc, M, N, K, split
     ('big TN 4096^2 x8192', 1, 1, 4096, 4096, 8192, 1),
     ('big NN 8192^2 x4096', 0, 1, 8192, 8192, 4096, 1),
 ]
+if os.environ.get('ONLY'): shapes = [x for x in shapes if x[0].startswith(os.environ['ONLY'])]
 variants = [int(x) for x in os.environ.get('VARIANTS', '0').split(',')]
 import itertools
 for (name, a_mc, b_nc, M, N, K, split), var in itertools.product(shapes, variants):

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from argsim_amd import lib
 l = lib.load()
-cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 0)
+cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, int(os.environ.get('DTYPE', '0')))
 h = C.c_void_p(); assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
 dev = torch.device('cuda', 0)
 a_mc, b_nc, M, N, K = [int(x) for x in sys.argv[1:6]]

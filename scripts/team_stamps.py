@@ -1,0 +1,20 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from argsim_amd import synth
+from argsim_amd.model import VAE
+m = VAE('train', seed=0, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+m.step = 20000
+ids = torch.as_tensor(synth.batch(256, 64, 8192, seed=0)).cuda()
+names = ['Aload+poll', 'mfma', 'barriers+write', 'gates+store', '-', 'loop']
+for ab in (128, 128 | 256):
+    for i in range(2): m.encode(ids)
+    m.set_option('gru_ablate', ab)
+    out = (C.c_uint64 * 32)()
+    m._l.avae_debug_stamps(m._h, out)
+    for i in range(3): m.encode(ids)
+    m._l.avae_debug_stamps(m._h, out)
+    m.set_option('gru_ablate', 0)
+    n, steps = out[10], out[8] / max(out[10], 1)
+    per = [out[i] / max(n, 1) / max(steps, 1) * 0.01 for i in range(6)]
+    print('ablate', ab, 'team-launches', n, 'steps %.1f' % steps, ' '.join('%s %.2f' % (a, b) for a, b in zip(names, per)), 'total %.2f us/step' % sum(per), flush=True)

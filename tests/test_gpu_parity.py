@@ -461,3 +461,95 @@ def test_bf16_mode_tracks_the_oracle(name):
     got = m.get_grads()
     bad = {k: rel_l2(got[k], grads[k]) for k in grads if rel_l2(got[k], grads[k]) > 5e-2}
     assert not bad, bad
+
+
+# ---------------------------------------------------------------- fp32 on the bf16 matrix cores (compute_dtype 2)
+@pytest.mark.parametrize("a_mc,b_nc", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 52), (4, 8, 16), (333, 260, 132), (1000, 512, 96), (256, 384, 4100)])
+def test_gemm_split_bf16_is_fp32_accurate(a_mc, b_nc, M, N, K):
+    """the 3 x bf16 split GEMM (6 partial products, fp32 accumulate) against float64 products of the SAME fp32
+    operands, at the tolerance of the exact-fp32 kernel's test (2e-5 of the result scale), on wide-range data"""
+    import torch
+    from argsim_amd import lib
+    l = lib.load()
+    if a_mc:
+        M = (M + 3) // 4 * 4
+    if b_nc:
+        N = (N + 3) // 4 * 4
+    rng = np.random.default_rng(M * 7 + N * 3 + K + 1)
+    A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)))).astype(np.float32)
+    B = (rng.standard_normal((K, N)) * np.exp(rng.standard_normal((K, N)))).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = 0.5 * (A.astype(np.float64) @ B.astype(np.float64)) + bias
+    scale = 0.5 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)) + 1.0
+    cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 2)
+    h = C.c_void_p()
+    assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
+    dev = torch.device('cuda', 0)
+    At = torch.tensor(A.T.copy() if a_mc else A, device=dev)
+    Bt = torch.tensor(B if b_nc else B.T.copy(), device=dev)
+    bt = torch.tensor(bias, device=dev)
+    for acc, split in ((0, 1), (1, 1), (0, 3)):
+        Ct = torch.tensor(C0, device=dev) if acc else torch.zeros((M, N), device=dev)
+        rc = l.avae_debug_gemm(h, a_mc, b_nc, At.data_ptr(), Bt.data_ptr(), Ct.data_ptr(), bt.data_ptr(),
+                               M, N, K, M if a_mc else K, N if b_nc else K, N, 0.5, acc, split)
+        assert rc == 0, l.avae_last_error(h)
+        torch.cuda.synchronize()
+        want = ref + (C0 if acc else 0.0)
+        got = Ct.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (acc, split)
+        # and in units of the fp32 accumulation error bound: a few 2^-24 of sum |a||b|
+        assert (np.abs(got - want) / scale).max() <= 2e-6, (acc, split)
+    l.avae_destroy(h)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_split_bf16_mode_meets_the_fp32_tolerances(name):
+    """the whole path with compute_dtype 2 is held to the SAME tolerances as the exact-fp32 path"""
+    cfg, P, ids, keep, eps = make_case(name)
+    m = _vae(cfg, P, dtype='f32s')
+    o = vn.forward(P, cfg, ids, ids, 'valid')
+    z, lv = m.encode(ids, return_lv=True)
+    assert np.abs(z - o['mu']).max() <= 2e-5
+    assert np.abs(lv - o['lv']).max() <= 2e-5
+    errt, lgen, lkld = m.eval(ids, ids)
+    assert np.abs(lgen - o['loss_gen_samp']).max() <= 1e-4
+    assert np.abs(lkld - o['loss_kld_samp']).max() <= 2e-5
+    step = 20000
+    m.step = step
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    lg, lk, lo = m.losses()
+    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, step, keep, eps)
+    assert abs(lg - outs['loss_gen']) <= 2e-5 * abs(outs['loss_gen'])
+    assert abs(lk - outs['loss_kld']) <= 2e-5 * abs(outs['loss_kld'])
+    got = m.get_grads()
+    bad = {k: rel_l2(got[k], grads[k]) for k in grads if rel_l2(got[k], grads[k]) > 2e-4}
+    assert not bad, bad
+
+
+def test_split_bf16_mode_at_bench_scale_tracks_exact_fp32():
+    """B=256, S=64, D=512, V=8192: z and the gradients of the split mode against the exact-fp32 MFMA path on the
+    same batch -- the difference must be of the size of fp32 rounding (both are fp32 computations of one graph)"""
+    import torch
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    kw = dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3, seed=0)
+    ids = synth.batch(256, 64, 8192, seed=0)
+    rng = np.random.default_rng(0)
+    keep = (rng.random((64, 256)) < 0.88).astype(np.uint8)
+    eps = rng.standard_normal((256, 128)).astype(np.float32)
+    res = {}
+    for dt in ('f32', 'f32s'):
+        m = VAE('train', dtype=dt, **kw)
+        m.step = 20000
+        z = m.encode(ids)
+        m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+        res[dt] = (z, m.losses(), m.get_grads())
+        del m
+        torch.cuda.empty_cache()
+    assert np.abs(res['f32'][0] - res['f32s'][0]).max() <= 2e-5
+    for a, b in zip(res['f32'][1], res['f32s'][1]):
+        assert abs(a - b) <= 2e-6 * abs(a)
+    bad = {k: rel_l2(res['f32s'][2][k], v) for k, v in res['f32'][2].items() if rel_l2(res['f32s'][2][k], v) > 1e-4}
+    assert not bad, bad
