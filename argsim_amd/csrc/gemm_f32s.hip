@@ -28,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SBK = 32;               // K tile
 constexpr int SLD = 32;               // LDS row stride in bf16: 64-byte rows, no padding, XOR-swizzled (below)
@@ -47,6 +48,14 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b)      // v_cvt_pk_bf
 {
     f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// x - y as one v_sub_f32: written in C the compiler pairs the residuals into v_pk_add_f32, which issues several
+// times slower than two v_sub_f32 here (measured on the split phase)
+__device__ __forceinline__ float sub_f32(float x, float y)
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 __device__ __forceinline__ float lo_f32(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float hi_f32(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
@@ -90,38 +99,107 @@ __device__ __forceinline__ void s_load(float4 (&r)[4], const float* __restrict__
     }
 }
 
+// Fast staging path (shapes whose tiles need no per-element predicate, see gemm_f32s()): raw buffer loads with
+// per-thread byte offsets computed once and a uniform (SGPR) base that advances per K tile; rows beyond the valid
+// region read as zero through the buffer's num_records, so the loop carries no exec-mask branch and no 64-bit
+// vector address arithmetic (which cost more vector issue slots than the split itself in the generic path).
+template <bool XC>
+struct FastSrc {
+    const float* base;      // tile origin at the first K tile of this slice
+    long long step;         // elements per K tile
+    long long valid;        // elements from base to the end of the valid region
+    unsigned voff[4];       // per-thread byte offsets of the four 16-byte pieces
+    __device__ __forceinline__ void init(const float* P, int ld, int x0, int X, int kb, int ke, int tid)
+    {
+        if (XC) {           // [k][x]: rows k < ke are valid
+            const int lane = tid & 63, kg = lane & 7, xg = (lane >> 3) + 8 * (tid >> 6);
+            base = P + (size_t)kb * ld + x0; step = (long long)SBK * ld; valid = (long long)(ke - kb) * ld - x0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) voff[e] = (unsigned)(((4 * kg + e) * ld + 4 * xg) * 4);
+        } else {            // [x][k]: rows x < X are valid, K is a multiple of the K tile
+            base = P + (size_t)x0 * ld + kb; step = SBK; valid = (long long)(X - x0) * ld - kb;
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) { const int f = tid + 256 * rep; voff[rep] = (unsigned)(((f >> 3) * ld + ((f & 7) << 2)) * 4); }
+        }
+    }
+    __device__ __forceinline__ void load(float4 (&r)[4], int it) const
+    {
+        const long long rem = valid - it * step;
+        const unsigned bytes = rem <= 0 ? 0u : (rem >= (1ll << 30) ? 0xFFFFFFFFu : (unsigned)(rem * 4));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + it * step), 0, (int)bytes, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[e], 0, 0);
+            r[e] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    }
+};
+
+// split + store of one operand's four 16-byte pieces.  The four pieces are carried through the split stage by
+// stage (all converts, then all residuals, ...) with scheduling barriers between the stages: written piece by
+// piece the compiler reuses ten registers and every instruction waits for its predecessor (measured: the
+// dependent chain cost ~14 cycles per instruction under the other waves' MFMA traffic, 3x the whole MFMA phase).
 template <bool XC, int ABL = 0>
 __device__ __forceinline__ void s_split_store(unsigned short* __restrict__ s, const float4 (&r)[4], int tid)
 {
+    float v[4][4];          // v[j][i]: piece j, i-th of its four consecutive k
+    int off[4];             // LDS element offset of piece j
     if (XC) {
         const int lane = tid & 63, kg = lane & 7, xg = (lane >> 3) + 8 * (tid >> 6);
-        // r[e] component xi = value at (k = 4 kg + e, x = 4 xg + xi)
+        // r[e] component xi = value at (k = 4 kg + e, x = 4 xg + xi): piece j = row 4 xg + j
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            uint2 ph, pm, pl;
-            split4(comp(r[0], xi), comp(r[1], xi), comp(r[2], xi), comp(r[3], xi), ph, pm, pl);
-            unsigned short* d = s + sw_off(4 * xg + xi, kg >> 1) + 4 * (kg & 1);
-            *reinterpret_cast<uint2*>(d) = ph;
-            *reinterpret_cast<uint2*>(d + SPLANE) = pm;
-            *reinterpret_cast<uint2*>(d + 2 * SPLANE) = pl;
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[j][i] = comp(r[i], j);
+            off[j] = sw_off(4 * xg + j, kg >> 1) + 4 * (kg & 1);
         }
     } else {
 #pragma unroll
-        for (int rep = 0; rep < 4; ++rep) {
-            const int f = tid + 256 * rep;
-            uint2 ph, pm, pl;
-            if (ABL & 1) { ph.x = cvt_pk(r[rep].x, r[rep].y); ph.y = cvt_pk(r[rep].z, r[rep].w); pm = ph; pl = ph; }
-            else split4(r[rep].x, r[rep].y, r[rep].z, r[rep].w, ph, pm, pl);
-            unsigned short* d = s + sw_off(f >> 3, (f & 7) >> 1) + 4 * (f & 1);
-            if (ABL & 2) { if (ph.x == 0x12345678u) *reinterpret_cast<uint2*>(d) = ph; continue; }
-            *reinterpret_cast<uint2*>(d) = ph;
-            *reinterpret_cast<uint2*>(d + SPLANE) = pm;
-            *reinterpret_cast<uint2*>(d + 2 * SPLANE) = pl;
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[j][i] = comp(r[j], i);
+            off[j] = sw_off(f >> 3, (f & 7) >> 1) + 4 * (f & 1);
         }
+    }
+    uint2 ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ph[j].x = cvt_pk(v[j][0], v[j][1]); ph[j].y = cvt_pk(v[j][2], v[j][3]); }
+    if (ABL & 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pm[j] = ph[j]; pl[j] = ph[j]; }
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j][0] = sub_f32(v[j][0], lo_f32(ph[j].x)); v[j][1] = sub_f32(v[j][1], hi_f32(ph[j].x));
+            v[j][2] = sub_f32(v[j][2], lo_f32(ph[j].y)); v[j][3] = sub_f32(v[j][3], hi_f32(ph[j].y));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pm[j].x = cvt_pk(v[j][0], v[j][1]); pm[j].y = cvt_pk(v[j][2], v[j][3]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j][0] = sub_f32(v[j][0], lo_f32(pm[j].x)); v[j][1] = sub_f32(v[j][1], hi_f32(pm[j].x));
+            v[j][2] = sub_f32(v[j][2], lo_f32(pm[j].y)); v[j][3] = sub_f32(v[j][3], hi_f32(pm[j].y));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pl[j].x = cvt_pk(v[j][0], v[j][1]); pl[j].y = cvt_pk(v[j][2], v[j][3]); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned short* d = s + off[j];
+        if (ABL & 2) { if (ph[j].x == 0x12345678u) *reinterpret_cast<uint2*>(d) = ph[j]; continue; }
+        *reinterpret_cast<uint2*>(d) = ph[j];
+        *reinterpret_cast<uint2*>(d + SPLANE) = pm[j];
+        *reinterpret_cast<uint2*>(d + 2 * SPLANE) = pl[j];
     }
 }
 
-template <bool A_MC, bool B_NC, int ABL = 0>
+template <bool A_MC, bool B_NC, int ABL = 0, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) unsigned short smem[6 * SPLANE];      // 48 KB: A hi|mid|lo, B hi|mid|lo
@@ -170,8 +248,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[4];
-    s_load<A_MC>(ra, g.A, g.lda, m0, M, kb, ke, tid);
-    s_load<B_NC>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    FastSrc<A_MC> fsa; FastSrc<B_NC> fsb;
+    if (FAST) {
+        fsa.init(g.A, g.lda, m0, M, kb, ke, tid); fsb.init(g.B, g.ldb, n0, g.N, kb, ke, tid);
+        fsa.load(ra, 0); fsb.load(rb, 0);
+    } else {
+        s_load<A_MC>(ra, g.A, g.lda, m0, M, kb, ke, tid);
+        s_load<B_NC>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    }
 
     // fragment (tile t, step s): row 64 w + 32 t + l31, chunk 2 s + h.  32 t flips neither swizzle term's low bits
     // beyond (r >> 2): rows r and r + 32 share r & 31, so (r >> 2) & 3 and (r >> 2) & 1 are equal for both tiles
@@ -186,15 +270,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
     for (int k0 = kb; k0 < ke; k0 += SBK) {
         if (ABL & 16) { __builtin_amdgcn_s_waitcnt(0x0F70 & 0xC07F); }      // vmcnt(0) only (gfx9 encoding: vmcnt lo [3:0], hi [15:14])
         AVAE_STAMP(0);
+        if (g.thin & 2) __builtin_amdgcn_s_setprio(3);       // experiment: staging phase above the other workgroups' MFMA phases
         s_split_store<A_MC, ABL>(As, ra, tid);
         s_split_store<B_NC, ABL>(Bs, rb, tid);
         AVAE_STAMP(1);
         __syncthreads();
         AVAE_STAMP(2);
         if (k0 + SBK < ke) {
-            s_load<A_MC>(ra, g.A, g.lda, m0, M, k0 + SBK, ke, tid);
-            s_load<B_NC>(rb, g.B, g.ldb, n0, g.N, k0 + SBK, ke, tid);
+            if (FAST) {
+                const int it = (k0 - kb) / SBK + 1;
+                fsa.load(ra, it); fsb.load(rb, it);
+            } else {
+                s_load<A_MC>(ra, g.A, g.lda, m0, M, k0 + SBK, ke, tid);
+                s_load<B_NC>(rb, g.B, g.ldb, n0, g.N, k0 + SBK, ke, tid);
+            }
         }
+        if (g.thin & 2) __builtin_amdgcn_s_setprio(0);
         AVAE_STAMP(3);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -272,25 +363,43 @@ hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     if (b_nc && (g.N & 3)) return hipErrorInvalidValue;
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
+    static const int prio = getenv("AVAE_F32S_PRIO") ? atoi(getenv("AVAE_F32S_PRIO")) : 0;
+    GemmArgs gp = g; gp.thin = prio ? 2 : 0;
     static const int abl = getenv("AVAE_F32S_ABLATE") ? atoi(getenv("AVAE_F32S_ABLATE")) : 0;     // timing experiments (wrong results)
     if (abl && !a_mc && !b_nc) {
         switch (abl) {
-        case 1: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 1>), grid, dim3(256), 0, st, g); break;
-        case 2: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 2>), grid, dim3(256), 0, st, g); break;
-        case 3: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 3>), grid, dim3(256), 0, st, g); break;
-        case 4: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 4>), grid, dim3(256), 0, st, g); break;
-        case 8: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 8>), grid, dim3(256), 0, st, g); break;
-        case 11: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 11>), grid, dim3(256), 0, st, g); break;
-        case 7: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 7>), grid, dim3(256), 0, st, g); break;
-        case 16: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16>), grid, dim3(256), 0, st, g); break;
+        case 1: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 1>), grid, dim3(256), 0, st, gp); break;
+        case 2: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 2>), grid, dim3(256), 0, st, gp); break;
+        case 3: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 3>), grid, dim3(256), 0, st, gp); break;
+        case 4: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 4>), grid, dim3(256), 0, st, gp); break;
+        case 8: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 8>), grid, dim3(256), 0, st, gp); break;
+        case 11: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 11>), grid, dim3(256), 0, st, gp); break;
+        case 7: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 7>), grid, dim3(256), 0, st, gp); break;
+        case 16: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16>), grid, dim3(256), 0, st, gp); break;
+        case 17: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16, true>), grid, dim3(256), 0, st, gp); break;
+        case 33: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 17, true>), grid, dim3(256), 0, st, gp); break;
+        case 34: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 18, true>), grid, dim3(256), 0, st, gp); break;
+        case 35: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 19, true>), grid, dim3(256), 0, st, gp); break;
+        case 36: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 20, true>), grid, dim3(256), 0, st, gp); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
-    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false>), grid, dim3(256), 0, st, g);
-    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true>), grid, dim3(256), 0, st, g);
-    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true>), grid, dim3(256), 0, st, g);
-    else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false>), grid, dim3(256), 0, st, g);
+    // fast staging path: no element of any tile needs a predicate the buffer bounds cannot express
+    //   k-contiguous operand: K a multiple of the K tile and known on the host;  [k][x] operand: x extent a multiple of 128
+    const bool fast = (a_mc ? (g.M % 128 == 0) : (g.K % SBK == 0 && g.dyn_kind != 2)) &&
+                      (b_nc ? (g.N % 128 == 0) : (g.K % SBK == 0 && g.dyn_kind != 2)) && abl != 99;
+    if (fast) {
+        if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 0, true>), grid, dim3(256), 0, st, gp);
+        else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true, 0, true>), grid, dim3(256), 0, st, gp);
+        else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true, 0, true>), grid, dim3(256), 0, st, gp);
+        else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false, 0, true>), grid, dim3(256), 0, st, gp);
+        return hipGetLastError();
+    }
+    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false>), grid, dim3(256), 0, st, gp);
+    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true>), grid, dim3(256), 0, st, gp);
+    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true>), grid, dim3(256), 0, st, gp);
+    else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false>), grid, dim3(256), 0, st, gp);
     return hipGetLastError();
 }
 

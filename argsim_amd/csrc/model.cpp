@@ -419,7 +419,9 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
     AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1));
-    AV_TRY(gemm(h, true, true, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, nullptr, 0, 1, w.ntok, 2));
+    // (V x D output = 256 tiles: one workgroup per CU cannot overlap its own staging; K = N rows split 3 ways fills
+    //  three workgroups per CU; G was zero-filled above and the gather part is scatter-added at the end)
+    AV_TRY(gemm(h, true, true, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, nullptr, 0, grad_split(V, D, rt), w.ntok, 2));
     // out affine
     AV_TRY(gemm_tn_grad(h, w.hc, D, w.dho, D, G + h->oKout, D, D, D, rt, 1.f, w.ntok));
     AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));

@@ -1,6 +1,6 @@
 """phase stamps of the split-bf16 GEMM main loop (AVAE_F32S_ABLATE=16): mean time per K tile of wave 0, per phase."""
 import ctypes as C, os, sys
-os.environ['AVAE_F32S_ABLATE'] = '16'
+os.environ.setdefault('AVAE_F32S_ABLATE', '16')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from argsim_amd import lib
