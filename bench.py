@@ -80,6 +80,7 @@ def main():
                     help="f32 = exact-fp32 MFMA (headline); f32s = fp32 GEMMs on the bf16 matrix cores by 3-way operand "
                          "splitting (fp32-accurate); bf16 = bf16 GEMM operands, fp32 everything else")
     ap.add_argument('--no-timing', action='store_true', help="skip the per-kernel HIP-event stamps (roofline leg)")
+    ap.add_argument('--no-alt', action='store_true', help="skip the extra f32s leg (same workload with the split-bf16 fp32 GEMMs)")
     ap.add_argument('--gru-stagger', type=int, default=0)
     ap.add_argument('--gru-item', type=int, default=-1, help="forward GRU kernel: 0 generic, 1 item pipeline, 2 four-team LDS-weight kernel")
     ap.add_argument('--gru-force-slow', action='store_true', help="never use the same-XCD L2 exchange path")
@@ -183,7 +184,7 @@ def main():
             traffic = None
             try:   # HBM bytes per launch of this kernel class from the separate rocprofv3 --pmc passes
                    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; scripts/summarize_profile.py)
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary%s.json' % ('' if A.dtype == 'f32' else '_' + A.dtype))))
                 if name == 'gemm':
                     traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
             except Exception:
@@ -198,6 +199,26 @@ def main():
                                                "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0)} for k, v in tm.items()}}
             if not A.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and A.dtype == 'f32' and not A.no_alt:
+            # same workload, same steps, GEMMs on the bf16 matrix cores with fp32-accurate operand splitting
+            # (opt-in mode, held to the fp32 tolerances by the parity tests): reported beside the headline, never as it
+            del model
+            torch.cuda.empty_cache()
+            m2 = VAE('train', device=local, seed=0, dtype='f32s', **CFG)
+            m2.step = 20000
+            for i in range(A.warmup):
+                m2.train_step(ids, ids, seed=i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(A.steps):
+                m2.train_step(ids, ids, seed=A.warmup + i)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            l2 = m2.losses()
+            assert all(x == x and abs(x) < 1e6 for x in l2), l2
+            out["f32s"] = {"value": B * A.steps / dt2, "unit": "sentences/sec", "ms_per_step": 1e3 * dt2 / A.steps, "loss": l2[2],
+                           "dtype": "f32 in / f32 accumulate / f32 out; GEMM operands split into 3 x bf16 in registers, 6 partial "
+                                    "products on v_mfma_f32_32x32x16_bf16 (VAE(dtype='f32s'), compute_dtype 2)"}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -7,11 +7,11 @@ bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is."""
 import collections, csv, glob, json, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-ks = glob.glob('gpurun_out/%s_trace/runc/*_kernel_stats.csv' % tag)[0]
+ks = glob.glob('gpurun_out/%s_trace/**/*kernel_stats.csv' % tag, recursive=True)[0]
 shutil.copy(ks, 'profiles/%s_kernel_stats.csv' % tag)
 out = {'units': 'bytes per dispatch (mean); fetch doubled per the gfx950 correction', 'kernels': {}}
 for nm in ('fetch', 'write'):
-    f = glob.glob('gpurun_out/%s_pmc_%s/runc/*_counter_collection.csv' % (tag, nm))[0]
+    f = glob.glob('gpurun_out/%s_pmc_%s/**/*counter_collection.csv' % (tag, nm), recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
@@ -24,7 +24,7 @@ for nm in ('fetch', 'write'):
 # class view used by bench.py: every gemm_f32_kernel instantiation together
 g = {'fetch': 0.0, 'write': 0.0, 'n': 0}
 for k, e in out['kernels'].items():
-    if 'gemm_f32_kernel' in k:
+    if 'gemm_f32_kernel' in k or 'gemm_f32s_kernel' in k:
         g['fetch'] += e.get('fetch_bytes', 0.0) * e.get('dispatches_fetch', 0)
         g['write'] += e.get('write_bytes', 0.0) * e.get('dispatches_write', 0)
         g['n'] += e.get('dispatches_fetch', 0)
