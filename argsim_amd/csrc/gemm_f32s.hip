@@ -352,6 +352,159 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
     }
 }
 
+// ---------------------------------------------------------------- wave-specialised form (fast-path shapes)
+// One 768-thread workgroup per CU: waves 0-3 ("consumers", one per SIMD) only read fragments and issue MFMAs,
+// waves 4-11 ("producers", two per SIMD) only load, split and store the NEXT K tile into the other half of a
+// double-buffered LDS image (2 x 48 KB).  One s_barrier per K tile.  In the phase-structured kernel above each
+// wave alternates between ~1900 cycles of vector work and 1536 cycles of MFMA and three workgroups per CU do not
+// line up well enough to keep the matrix pipe busy (60 % measured); here the pipe's wave never leaves the MFMA
+// stream and the split runs beside it on the same SIMD (vector issue: 48 x 8 cycles of MFMA + ~180 x 4 cycles of
+// split per 1536-cycle K tile).
+template <bool A_MC, bool B_NC>
+__global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];      // 2 stages x (A hi|mid|lo, B hi|mid|lo)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+
+    int M = g.M, K = g.K;
+    if (g.dyn_kind == 1) M = min(M, *g.dyn);
+    if (g.dyn_kind == 2) K = min(K, *g.dyn);
+    const int tiles_n = (g.N + 127) / 128, tiles_m = (g.M + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int grp = bid / (8 * tiles_n), rem = bid - grp * 8 * tiles_n;
+    const int gm = min(8, tiles_m - 8 * grp);
+    const int tn = rem / gm, tm = 8 * grp + rem - tn * gm;
+    const int m0 = tm * 128, n0 = tn * 128;
+    if (m0 >= M) return;                                  // uniform over the workgroup
+    int kb = 0, ke = K;
+    if (g.split_k > 1) {
+        const int ktiles = (K + SBK - 1) / SBK, per = (ktiles + g.split_k - 1) / g.split_k;
+        kb = blockIdx.z * per * SBK;
+        ke = min(K, kb + per * SBK);
+        if (kb >= ke) return;
+    }
+    const int nk = (ke - kb + SBK - 1) / SBK;
+
+    if (producer) {
+        // waves 4-7 stage the A operand, waves 8-11 the B operand (256 threads each, the staging map of the
+        // phase-structured kernel): two producer waves per SIMD run their dependent split chains side by side
+        const bool isb = wave >= 8;
+        const int ptid = tid - (isb ? 512 : 256);
+        float4 r[4];
+        if (!isb) {
+            FastSrc<A_MC> fs;
+            fs.init(g.A, g.lda, m0, M, kb, ke, ptid);
+            fs.load(r, 0);
+            s_split_store<A_MC>(dsm, r, ptid);
+            if (nk > 1) fs.load(r, 1);
+            __syncthreads();
+            for (int it = 0; it < nk; ++it) {
+                if (it + 1 < nk) {
+                    s_split_store<A_MC>(dsm + ((it + 1) & 1) * 6 * SPLANE, r, ptid);
+                    if (it + 2 < nk) fs.load(r, it + 2);
+                }
+                __syncthreads();
+            }
+        } else {
+            FastSrc<B_NC> fs;
+            fs.init(g.B, g.ldb, n0, g.N, kb, ke, ptid);
+            fs.load(r, 0);
+            s_split_store<B_NC>(dsm + 3 * SPLANE, r, ptid);
+            if (nk > 1) fs.load(r, 1);
+            __syncthreads();
+            for (int it = 0; it < nk; ++it) {
+                if (it + 1 < nk) {
+                    s_split_store<B_NC>(dsm + ((it + 1) & 1) * 6 * SPLANE + 3 * SPLANE, r, ptid);
+                    if (it + 2 < nk) fs.load(r, it + 2);
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ---- consumers
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    int offa[2], offb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { offa[s] = sw_off(64 * wm + l31, 2 * s + h); offb[s] = 3 * SPLANE + sw_off(64 * wn + l31, 2 * s + h); }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (g.thin & 2) __builtin_amdgcn_s_setprio(2);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const unsigned short* st = dsm + (it & 1) * 6 * SPLANE;
+        bf16x8 a[2][2][3], b[2][2][3];          // [step][tile][plane]: all 24 fragments of the K tile in flight at once
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offa[s] + p * SPLANE + 32 * t * SLD));
+                    b[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offb[s] + p * SPLANE + 32 * t * SLD));
+                }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#define AVAE_PROD(pa, pb)                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][pa], b[s][j][pb], acc[i][j], 0, 0, 0);
+            AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) AVAE_PROD(0, 0)
+#undef AVAE_PROD
+        }
+        __syncthreads();
+    }
+    if (g.thin & 2) __builtin_amdgcn_s_setprio(0);
+
+    const bool atomic = g.split_k > 1;
+    const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 64 * wn + 32 * j + l31;
+        if (col >= g.N) continue;
+        const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                const float v = g.alpha * acc[i][j][r] + bv;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+template <bool A_MC, bool B_NC>
+static hipError_t launch_ws(hipStream_t st, dim3 grid, const GemmArgs& g)
+{
+    constexpr int lds_bytes = 2 * 6 * SPLANE * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32s_ws_kernel<A_MC, B_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32s_ws_kernel<A_MC, B_NC>), grid, dim3(768), lds_bytes, st, g);
+    return hipGetLastError();
+}
+
 hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
 {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
@@ -389,6 +542,16 @@ hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     //   k-contiguous operand: K a multiple of the K tile and known on the host;  [k][x] operand: x extent a multiple of 128
     const bool fast = (a_mc ? (g.M % 128 == 0) : (g.K % SBK == 0 && g.dyn_kind != 2)) &&
                       (b_nc ? (g.N % 128 == 0) : (g.K % SBK == 0 && g.dyn_kind != 2)) && abl != 99;
+    static const int ws = getenv("AVAE_F32S_WS") ? atoi(getenv("AVAE_F32S_WS")) : 1;      // 0: phase-structured kernel (A/B experiments)
+    // one 768-thread workgroup per CU pays ~9 us per tile that nothing overlaps (first loads, C stores, dispatch):
+    // it wins where a workgroup's K extent is long (measured cross-over between K = 1024 and 1536)
+    const int k_per_wg = g.split_k > 1 ? (g.K + g.split_k - 1) / g.split_k : g.K;
+    if (fast && (ws == 2 || (ws == 1 && k_per_wg >= 1536))) {
+        if (!a_mc && !b_nc)      return launch_ws<false, false>(st, grid, gp);
+        else if (!a_mc && b_nc)  return launch_ws<false, true>(st, grid, gp);
+        else if (a_mc && b_nc)   return launch_ws<true, true>(st, grid, gp);
+        else                     return launch_ws<true, false>(st, grid, gp);
+    }
     if (fast) {
         if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 0, true>), grid, dim3(256), 0, st, gp);
         else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true, 0, true>), grid, dim3(256), 0, st, gp);
