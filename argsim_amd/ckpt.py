@@ -14,7 +14,11 @@ tf.contrib.cudnn_rnn, NOT verifiable offline):
         gates/kernel (In+D, 2D) [r | u]      gates/bias (2D) = bW + bR
         candidate/input_projection/{kernel (In,D), bias (D)}
         candidate/hidden_projection/{kernel (D,D), bias (D)}
-Reading/writing the TF bundle files themselves is SURVEY 8(f) item 4 (next)."""
+``save_tf`` / ``restore_tf`` write and read the TF V2 checkpoint files themselves (``tf_bundle.py``:
+<prefix>.index + <prefix>.data-00000-of-00001 + ``checkpoint``) under those names, with the Adam slots of
+the GRU weights in the flat cuDNN "opaque kernel" layout TF keeps them in (all weight matrices
+W_r,W_u,W_n,R_r,R_u,R_n layer by layer, then all biases) -- SURVEY 8(f) item 4.  Byte compatibility with a
+real TF process is unverified here (no TensorFlow, no reference checkpoint): parity unpinned."""
 import re
 
 import numpy as np
@@ -58,7 +62,11 @@ def save(vae, path, slots=True):
 
 
 def restore(vae, path, strict=True):
-    """saver.restore(sess, path)  (src/train.py:93-94)"""
+    """saver.restore(sess, path)  (src/train.py:93-94).  A TF V2 checkpoint prefix (``<path>.index`` exists)
+    is read through ``restore_tf``; otherwise the native ``.npz``."""
+    import os
+    if os.path.exists(path + '.index'):
+        return restore_tf(vae, path, strict)
     if not path.endswith('.npz'):
         path += '.npz'
     with np.load(path, allow_pickle=False) as f:
@@ -116,3 +124,81 @@ def from_tf_names(sd, names):
         out[base + 'bW'] = np.concatenate([gb, np.asarray(sd[p + 'candidate/input_projection/bias'])])
         out[base + 'bR'] = np.concatenate([np.zeros_like(gb), np.asarray(sd[p + 'candidate/hidden_projection/bias'])])
     return out
+
+
+# ------------------------------------------------------------------ TF V2 checkpoint files
+def _opaque_groups(names):
+    """{tf scope: [per layer: native base name 'encode/rnn1/fwd/' ...]} in cuDNN layer order"""
+    groups = {}
+    for k in names:
+        if _GRU.match(k) and k.endswith('/W'):
+            scope, cell = _tf_scope(k)
+            groups.setdefault(scope, {})[cell] = k[:-1]
+    return {sc: [g[c] for c in sorted(g)] for sc, g in groups.items()}
+
+
+def _to_opaque(get, bases):
+    """flat cuDNN GRU parameter buffer of one CudnnGRU op from native (3D, In) gate-stacked tensors"""
+    ws, bs = [], []
+    for b in bases:
+        W, R, bW, bR = (np.asarray(get(b + n)) for n in ('W', 'R', 'bW', 'bR'))
+        D = R.shape[1]
+        ws += [W[g * D:(g + 1) * D].ravel() for g in range(3)] + [R[g * D:(g + 1) * D].ravel() for g in range(3)]
+        bs += [bW[g * D:(g + 1) * D] for g in range(3)] + [bR[g * D:(g + 1) * D] for g in range(3)]
+    return np.concatenate(ws + bs).astype(np.float32)
+
+
+def _from_opaque(flat, bases, shapes):
+    out, pos = {}, 0
+    flat = np.asarray(flat).ravel()
+    for b in bases:
+        D, In = shapes[b + 'R'][1], shapes[b + 'W'][1]
+        W = flat[pos:pos + 3 * D * In].reshape(3 * D, In); pos += 3 * D * In
+        R = flat[pos:pos + 3 * D * D].reshape(3 * D, D); pos += 3 * D * D
+        out[b + 'W'], out[b + 'R'] = W, R
+    for b in bases:
+        D = shapes[b + 'R'][1]
+        out[b + 'bW'] = flat[pos:pos + 3 * D]; pos += 3 * D
+        out[b + 'bR'] = flat[pos:pos + 3 * D]; pos += 3 * D
+    assert pos == flat.size, "opaque kernel size does not match the GRU geometry"
+    return out
+
+
+def save_tf(vae, prefix, slots=True):
+    """saver.save(sess, prefix, write_meta_graph=False) as TF V2 checkpoint files (src/train.py:121)"""
+    from . import tf_bundle
+    sd = state_dict(vae, slots)
+    out = to_tf_names({k: v for k, v in sd.items() if not k.startswith('train/')})
+    if slots:
+        groups = _opaque_groups(vae.names)
+        in_gru = {b + n for bases in groups.values() for b in bases for n in ('W', 'R', 'bW', 'bR')}
+        for slot in ('Adam', 'Adam_1'):
+            for k in vae.names:
+                if k not in in_gru:
+                    out['train/%s/%s' % (k, slot)] = sd['train/%s/%s' % (k, slot)]
+            for scope, bases in groups.items():
+                out['train/%s/cudnn_gru/opaque_kernel/%s' % (scope, slot)] = _to_opaque(lambda n: sd['train/%s/%s' % (n, slot)], bases)
+        t = float(vae.step) + 1.0
+        out['train/beta1_power'] = np.asarray(0.9 ** t, np.float32)
+        out['train/beta2_power'] = np.asarray(0.999 ** t, np.float32)
+    tf_bundle.write_bundle(prefix, out)
+    return prefix
+
+
+def restore_tf(vae, prefix, strict=True):
+    """saver.restore(sess, prefix) from TF V2 checkpoint files (src/train.py:93-94, eval_embed_reason.py:24-27)"""
+    from . import tf_bundle
+    raw = tf_bundle.read_bundle(prefix)
+    sd = from_tf_names({k: v for k, v in raw.items() if not k.startswith('train/')}, vae.names)
+    groups = _opaque_groups(vae.names)
+    in_gru = {b + n for bases in groups.values() for b in bases for n in ('W', 'R', 'bW', 'bR')}
+    for slot in ('Adam', 'Adam_1'):
+        for k in vae.names:
+            if k not in in_gru and 'train/%s/%s' % (k, slot) in raw:
+                sd['train/%s/%s' % (k, slot)] = raw['train/%s/%s' % (k, slot)]
+        for scope, bases in groups.items():
+            key = 'train/%s/cudnn_gru/opaque_kernel/%s' % (scope, slot)
+            if key in raw:
+                for n, v in _from_opaque(raw[key], bases, vae.shapes).items():
+                    sd['train/%s/%s' % (n, slot)] = v
+    load_state_dict(vae, sd, strict)

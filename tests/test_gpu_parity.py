@@ -553,3 +553,39 @@ def test_split_bf16_mode_at_bench_scale_tracks_exact_fp32():
         assert abs(a - b) <= 2e-6 * abs(a)
     bad = {k: rel_l2(res['f32s'][2][k], v) for k, v in res['f32'][2].items() if rel_l2(res['f32s'][2][k], v) > 1e-4}
     assert not bad, bad
+
+
+def test_tf_checkpoint_files_roundtrip(tmp_path):
+    """save_tf -> TF V2 checkpoint files (index table + data shard, canonical CudnnGRU names, opaque Adam slots)
+    -> restore into a fresh model: parameters, Adam slots, step and z are reproduced exactly except that TF's
+    canonical form stores the r/u biases summed (restored as bW = sum, bR = 0: the same function)"""
+    from argsim_amd import ckpt, tf_bundle
+    cfg, P, ids, keep, eps = make_case('mid')
+    m = _vae(cfg, P)
+    m.step = 777
+    for i in range(2):
+        m.train_step(ids, ids, keep_mask=keep, eps=eps)
+    z0 = m.encode(ids)
+    prefix = ckpt.save_tf(m, str(tmp_path / 'ckpt' / 'trial_3'))
+    names = set(tf_bundle.read_bundle(prefix))
+    assert 'global_step' in names and 'embed/embedding' in names and 'train/beta1_power' in names
+    assert 'encode/rnn1/fwd/cudnn_gru/rnn/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/gates/kernel' in names
+    assert 'train/decode/rnn/cudnn_gru/opaque_kernel/Adam_1' in names
+    m2 = _vae(cfg, {k: np.zeros_like(v) for k, v in P.items()})
+    ckpt.restore(m2, prefix)                       # auto-detects the TF prefix
+    assert m2.step == m.step
+    assert np.abs(m2.encode(ids) - z0).max() <= 1e-6
+    a, b = m.get_params(), m2.get_params()
+    for k in a:
+        if k.endswith('/bW') or k.endswith('/bR'):
+            continue
+        assert np.array_equal(a[k], b[k]), k
+    from argsim_amd.model import ADAM_M, ADAM_V
+    for kind in (ADAM_M, ADAM_V):
+        sa, sb = m.get_params(kind), m2.get_params(kind)
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), (kind, k)
+    # and training continues from the restored state like from the original
+    m.train_step(ids, ids, keep_mask=keep, eps=eps)
+    m2.train_step(ids, ids, keep_mask=keep, eps=eps)
+    assert abs(m.losses()[2] - m2.losses()[2]) <= 1e-5 * abs(m.losses()[2])
