@@ -71,6 +71,7 @@ def cpu_baseline(sample_b=32, steps=2):
 
 
 def main():
+    global B, S
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -80,6 +81,8 @@ def main():
                     help="f32 = exact-fp32 MFMA (headline); f32s = fp32 GEMMs on the bf16 matrix cores by 3-way operand "
                          "splitting (fp32-accurate); bf16 = bf16 GEMM operands, fp32 everything else")
     ap.add_argument('--no-timing', action='store_true', help="skip the per-kernel HIP-event stamps (roofline leg)")
+    ap.add_argument('--batch', type=int, default=B, help="rows per GPU (default: BASELINE configs[1]; 1024 = configs[2]/[3] per-GPU load)")
+    ap.add_argument('--seq', type=int, default=S, help="sequence length (default 64; 128 = configs[2])")
     ap.add_argument('--no-alt', action='store_true', help="skip the extra f32s leg (same workload with the split-bf16 fp32 GEMMs)")
     ap.add_argument('--gru-stagger', type=int, default=0)
     ap.add_argument('--gru-item', type=int, default=-1, help="forward GRU kernel: 0 generic, 1 item pipeline, 2 four-team LDS-weight kernel")
@@ -87,6 +90,8 @@ def main():
     ap.add_argument('--gru-ablate', type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument('--stepwise', action='store_true', help="one GRU launch per time step instead of the persistent kernels")
     A = ap.parse_args()
+    headline = (A.batch, A.seq) == (B, S)
+    B, S = A.batch, A.seq
 
     import torch
     import torch.distributed as dist
@@ -166,7 +171,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f32s": "f32 (GEMM operands split into 3 x bf16 in registers, 6 partial products, f32 accumulate)",
                       "bf16": "bf16 GEMM operands, f32 accumulate/recurrence/state/Adam"}[A.dtype], "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1xMI355X %s, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
+            "config": {"workload": ("" if headline else "NOT the headline workload (batch %d x seq %d per GPU) -- " % (B, S)) +
+                                   "BASELINE configs[1]: 1xMI355X %s, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
                                    "FULL synthetic Zipf batches, dim_emb 512, 3 layers, step 20000"
                                    % {"f32": "fp32", "f32s": "fp32 (split-bf16 MFMA GEMMs, fp32-accurate)",
                                       "bf16": "(bf16 GEMM operands: the opt-in mode of configs[2], same shapes)"}[A.dtype],
@@ -199,7 +205,7 @@ def main():
                                                "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0)} for k, v in tm.items()}}
             if not A.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
-        if world == 1 and A.dtype == 'f32' and not A.no_alt:
+        if world == 1 and A.dtype == 'f32' and not A.no_alt and headline:
             # same workload, same steps, GEMMs on the bf16 matrix cores with fp32-accurate operand splitting
             # (opt-in mode, held to the fp32 tolerances by the parity tests): reported beside the headline, never as it
             del model
