@@ -280,6 +280,9 @@ hipError_t latent_bwd(hipStream_t st, const float* dz, const float* mu, const fl
 // ---------------------------------------------------------------- softmax cross-entropy (model.py:170-181)
 // one workgroup per compact row: pass 1 online max / sum-exp / first-argmax / label pick,
 // pass 2 (optional) overwrites the row with (softmax - onehot) * scale.
+// REG: V <= 8192 -- the row (<= 32 floats per thread) is read ONCE and stays in registers between the two passes
+// (1 read + 1 write of the logits instead of 2 + 1: this kernel is HBM-bound)
+template <bool REG>
 __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
 {
     __shared__ float s_m[4], s_s[4], s_bv[4]; __shared__ int s_bi[4];
@@ -293,8 +296,19 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
         float* x = a.logits + (size_t)row * a.V;
         const int label = a.gold[a.cidx[row]];
         float m = -INFINITY, s = 0.f, bv = -INFINITY; int bi = 0x7fffffff;
-        for (int c = tid * 4; c < a.V; c += 1024) {
-            float4 v = *reinterpret_cast<const float4*>(x + c);
+        float4 keep[REG ? 8 : 1];
+        if (REG) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = tid * 4 + 1024 * q;
+                keep[q] = c < a.V ? *reinterpret_cast<const float4*>(x + c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (REG ? 8 : (1 << 20)); ++q) {
+            const int c = tid * 4 + 1024 * q;
+            if (c >= a.V) break;
+            float4 v = REG ? keep[REG ? q : 0] : *reinterpret_cast<const float4*>(x + c);
             float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -333,8 +347,11 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
         }
         if (a.write_grad) {
             __syncthreads();     // x[label] read before overwrite
-            for (int c = tid * 4; c < a.V; c += 1024) {
-                float4 v = *reinterpret_cast<const float4*>(x + c);
+#pragma unroll
+            for (int q = 0; q < (REG ? 8 : (1 << 20)); ++q) {
+                const int c = tid * 4 + 1024 * q;
+                if (c >= a.V) break;
+                float4 v = REG ? keep[REG ? q : 0] : *reinterpret_cast<const float4*>(x + c);
                 float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] = (expf(e[k] - lse) - ((c + k) == label ? 1.f : 0.f)) * scale;
@@ -349,7 +366,8 @@ hipError_t softmax_ce(hipStream_t st, const CeArgs& a)
 {
     if (a.n_max <= 0) return hipSuccess;
     if (a.V & 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    if (a.V <= 8192) hipLaunchKernelGGL(softmax_ce_kernel<true>, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    else             hipLaunchKernelGGL(softmax_ce_kernel<false>, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
