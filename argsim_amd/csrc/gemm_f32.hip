@@ -11,6 +11,7 @@
 // Within a 32-deep K tile, MFMA step j (0..15) of lane-half h consumes k = 8*(j>>2) + 4*h + (j&3):
 // a k-contiguous operand row then feeds four consecutive steps from ONE ds_read_b128.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace avae {
 
@@ -50,10 +51,43 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (
     }
 }
 
+// Fast staging (shapes whose tiles need no per-element predicate, see gemm_f32()): raw buffer loads with per-thread
+// byte offsets computed once and a uniform (SGPR) base that advances per K tile; rows beyond the valid region read
+// as zero through the buffer's num_records.  The predicated path above spends ~650 vector instructions per wave
+// and K tile on exec-mask branches and 64-bit address arithmetic; this one ~20.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool XC, int ROWS>
+struct FastTile {
+    const float* base; long long step, valid; unsigned voff[ROWS / 32];
+    __device__ __forceinline__ void init(const float* P, int ld, int x0, int X, int kb, int ke, int tid)
+    {
+        if (XC) {           // [k][x]: rows k < ke valid; x extent a multiple of ROWS
+            base = P + (size_t)kb * ld + x0; step = (long long)BK * ld; valid = (long long)(ke - kb) * ld - x0;
+#pragma unroll
+            for (int rep = 0; rep < ROWS / 32; ++rep) { const int f = tid + 256 * rep; voff[rep] = (unsigned)(((f / (ROWS / 4)) * ld + ((f % (ROWS / 4)) << 2)) * 4); }
+        } else {            // [x][k]: rows x < X valid; K a multiple of BK
+            base = P + (size_t)x0 * ld + kb; step = BK; valid = (long long)(X - x0) * ld - kb;
+#pragma unroll
+            for (int rep = 0; rep < ROWS / 32; ++rep) { const int f = tid + 256 * rep; voff[rep] = (unsigned)(((f >> 3) * ld + ((f & 7) << 2)) * 4); }
+        }
+    }
+    __device__ __forceinline__ void load(float4 (&r)[ROWS / 32], int it) const
+    {
+        const long long rem = valid - it * step;
+        const unsigned bytes = rem <= 0 ? 0u : (rem >= (1ll << 30) ? 0xFFFFFFFFu : (unsigned)(rem * 4));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + it * step), 0, (int)bytes, 0x00020000);
+#pragma unroll
+        for (int rep = 0; rep < ROWS / 32; ++rep) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[rep], 0, 0);
+            r[rep] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    }
+};
+
 // WM x WN waves (WM*WN = 4), each TM x TN MFMA tiles of 32x32: block tile BM = 32 WM TM, BN = 32 WN TN.
 // <2,2,2,2> = 128x128 is the workhorse; <1,4,1,1> = 32x128 serves thin row panels (M <= 512 and the
 // remainder rows of a tile count just above a multiple of 256) deterministically, without split-K.
-template <bool A_MC, bool B_NC, int WM, int WN, int TM, int TN>
+template <bool A_MC, bool B_NC, int WM, int WN, int TM, int TN, bool FAST = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -101,16 +135,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
-    load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, kb, ke, tid);
-    load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    FastTile<A_MC, BM> fa; FastTile<B_NC, BN> fb;
+    if (FAST) {
+        fa.init(g.A, g.lda, m0, M, kb, ke, tid); fb.init(g.B, g.ldb, n0, g.N, kb, ke, tid);
+        fa.load(ra, 0); fb.load(rb, 0);
+    } else {
+        load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, kb, ke, tid);
+        load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    }
 
     for (int k0 = kb; k0 < ke; k0 += BK) {
         store_tile<A_MC, BM>(As, ra, tid);
         store_tile<B_NC, BN>(Bs, rb, tid);
         __syncthreads();
         if (k0 + BK < ke) {
-            load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
-            load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
+            if (FAST) {
+                const int it = (k0 - kb) / BK + 1;
+                fa.load(ra, it); fb.load(rb, it);
+            } else {
+                load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
+                load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -176,6 +221,20 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
+    // fast staging: k-contiguous operand: K a multiple of BK, known on the host; [k][x] operand: x extent a multiple of the tile
+    static const bool allow_fast = !getenv("AVAE_F32_NOFAST");
+    // (measured: +4..9 % where an operand is stored [k][x] or the K extent is long; the NT shapes with K <= 1024
+    //  lose 1..7 % to the longer prologue and stay on the predicated path)
+    const int k_per_wg = g.split_k > 1 ? (g.K + g.split_k - 1) / g.split_k : g.K;
+    const bool fast = allow_fast && (a_mc ? (g.M % BM == 0) : (g.K % BK == 0 && g.dyn_kind != 2)) &&
+                      (b_nc ? (g.N % BN == 0) : (g.K % BK == 0 && g.dyn_kind != 2)) && (a_mc || b_nc || k_per_wg >= 1536);
+    if (fast) {
+        if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g);
+        else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g);
+        else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g);
+        else                     hipLaunchKernelGGL((gemm_f32_kernel<true, false, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g);
+        return;
+    }
     if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
     else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
     else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
