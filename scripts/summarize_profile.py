@@ -24,7 +24,7 @@ for nm in ('fetch', 'write'):
 # class view used by bench.py: every gemm_f32_kernel instantiation together
 g = {'fetch': 0.0, 'write': 0.0, 'n': 0}
 for k, e in out['kernels'].items():
-    if 'gemm_f32_kernel' in k or 'gemm_f32s_kernel' in k:
+    if 'gemm_f32' in k:
         g['fetch'] += e.get('fetch_bytes', 0.0) * e.get('dispatches_fetch', 0)
         g['write'] += e.get('write_bytes', 0.0) * e.get('dispatches_write', 0)
         g['n'] += e.get('dispatches_fetch', 0)
