@@ -16,9 +16,13 @@
 // split-K with float atomics.  Operands stay fp32 in HBM: no conversion pass, no extra traffic.
 //
 // Block tile 128x128x32, 4 waves (2x2), each 2x2 MFMA tiles of 32x32.  LDS holds three bf16 planes per operand,
-// rows k-contiguous with an 80-byte stride: a fragment (lane (r, h): 8 consecutive k at 16 s + 8 h of row r) is
-// one conflict-free ds_read_b128.  Operands stored [k][x] are transposed in registers (a thread loads a 4x4
-// patch) so that LDS never sees a 2-byte access.
+// 64-byte k-contiguous rows, XOR-swizzled (sw_off) so that the ds_read_b128 fragment reads (lane (r, h): 8
+// consecutive k at 16 s + 8 h of row r) and both kinds of staging stores are bank-conflict free.  Operands stored
+// [k][x] are transposed in registers (a thread loads a 4x4 patch) so that LDS never sees a 2-byte access.
+// Two kernels: gemm_f32s_kernel (three workgroups per CU alternate staging and MFMA phases; all shapes) and
+// gemm_f32s_ws_kernel (wave-specialised: 4 MFMA waves + 8 staging waves per CU, double-buffered LDS; long-K
+// shapes).  s_setprio on either phase, deeper load prefetch and a hand-interleaved single-wave-per-SIMD form were
+// measured and brought nothing.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -165,10 +169,7 @@ __device__ __forceinline__ void s_split_store(unsigned short* __restrict__ s, co
     uint2 ph[4], pm[4], pl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ph[j].x = cvt_pk(v[j][0], v[j][1]); ph[j].y = cvt_pk(v[j][2], v[j][3]); }
-    if (ABL & 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { pm[j] = ph[j]; pl[j] = ph[j]; }
-    } else {
+    {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -192,7 +193,6 @@ __device__ __forceinline__ void s_split_store(unsigned short* __restrict__ s, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         unsigned short* d = s + off[j];
-        if (ABL & 2) { if (ph[j].x == 0x12345678u) *reinterpret_cast<uint2*>(d) = ph[j]; continue; }
         *reinterpret_cast<uint2*>(d) = ph[j];
         *reinterpret_cast<uint2*>(d + SPLANE) = pm[j];
         *reinterpret_cast<uint2*>(d + 2 * SPLANE) = pl[j];
@@ -270,7 +270,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
     for (int k0 = kb; k0 < ke; k0 += SBK) {
         if (ABL & 16) { __builtin_amdgcn_s_waitcnt(0x0F70 & 0xC07F); }      // vmcnt(0) only (gfx9 encoding: vmcnt lo [3:0], hi [15:14])
         AVAE_STAMP(0);
-        if (g.thin & 2) __builtin_amdgcn_s_setprio(3);       // experiment: staging phase above the other workgroups' MFMA phases
         s_split_store<A_MC, ABL>(As, ra, tid);
         s_split_store<B_NC, ABL>(Bs, rb, tid);
         AVAE_STAMP(1);
@@ -285,20 +284,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
                 s_load<B_NC>(rb, g.B, g.ldb, n0, g.N, k0 + SBK, ke, tid);
             }
         }
-        if (g.thin & 2) __builtin_amdgcn_s_setprio(0);
         AVAE_STAMP(3);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 a[2][3], b[2][3];
-            if ((ABL & 8) && s == 1) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        a[t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + offa[0] + 32 * t * SLD));
-                        b[t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + offb[0] + 32 * t * SLD));
-                    }
-            } else
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -311,8 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
-            if (!(ABL & 4)) { AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) }
-            AVAE_PROD(0, 0)
+            AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) AVAE_PROD(0, 0)
 #undef AVAE_PROD
         }
         __syncthreads();
@@ -441,7 +429,6 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (g.thin & 2) __builtin_amdgcn_s_setprio(2);
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
         const unsigned short* st = dsm + (it & 1) * 6 * SPLANE;
@@ -466,7 +453,6 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
         }
         __syncthreads();
     }
-    if (g.thin & 2) __builtin_amdgcn_s_setprio(0);
 
     const bool atomic = g.split_k > 1;
     const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
@@ -516,26 +502,12 @@ hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     if (b_nc && (g.N & 3)) return hipErrorInvalidValue;
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
-    static const int prio = getenv("AVAE_F32S_PRIO") ? atoi(getenv("AVAE_F32S_PRIO")) : 0;
-    GemmArgs gp = g; gp.thin = prio ? 2 : 0;
-    static const int abl = getenv("AVAE_F32S_ABLATE") ? atoi(getenv("AVAE_F32S_ABLATE")) : 0;     // timing experiments (wrong results)
-    if (abl && !a_mc && !b_nc) {
-        switch (abl) {
-        case 1: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 1>), grid, dim3(256), 0, st, gp); break;
-        case 2: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 2>), grid, dim3(256), 0, st, gp); break;
-        case 3: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 3>), grid, dim3(256), 0, st, gp); break;
-        case 4: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 4>), grid, dim3(256), 0, st, gp); break;
-        case 8: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 8>), grid, dim3(256), 0, st, gp); break;
-        case 11: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 11>), grid, dim3(256), 0, st, gp); break;
-        case 7: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 7>), grid, dim3(256), 0, st, gp); break;
-        case 16: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16>), grid, dim3(256), 0, st, gp); break;
-        case 17: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16, true>), grid, dim3(256), 0, st, gp); break;
-        case 33: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 17, true>), grid, dim3(256), 0, st, gp); break;
-        case 34: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 18, true>), grid, dim3(256), 0, st, gp); break;
-        case 35: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 19, true>), grid, dim3(256), 0, st, gp); break;
-        case 36: hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 20, true>), grid, dim3(256), 0, st, gp); break;
-        default: return hipErrorInvalidValue;
-        }
+    const GemmArgs& gp = g;
+    static const int abl = getenv("AVAE_F32S_ABLATE") ? atoi(getenv("AVAE_F32S_ABLATE")) : 0;     // diagnostics only
+    if (abl && !a_mc && !b_nc) {         // 16 / 17: phase stamps of the predicated / fast-staging main loop (scripts/gemm_stamps.py)
+        if (abl == 16)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16>), grid, dim3(256), 0, st, gp);
+        else if (abl == 17) hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16, true>), grid, dim3(256), 0, st, gp);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     // fast staging path: no element of any tile needs a predicate the buffer bounds cannot express
