@@ -25,6 +25,7 @@
 // measured and brought nothing.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace avae {
 
@@ -348,8 +349,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
 // line up well enough to keep the matrix pipe busy (60 % measured); here the pipe's wave never leaves the MFMA
 // stream and the split runs beside it on the same SIMD (vector issue: 48 x 8 cycles of MFMA + ~180 x 4 cycles of
 // split per 1536-cycle K tile).
+// the tiles one workgroup works through: virtual block ids blockIdx.x, + gridDim.x, ... through the XCD-aware grouped
+// order; tiles beyond the device-side row count are skipped (both roles walk the same sequence)
+struct TileIter {
+    int vb, step, nblk, tiles_m, tiles_n, M, m0, n0; bool ok;
+    __device__ __forceinline__ void seek()
+    {
+        for (ok = false; vb < nblk; vb += step) {
+            const int q = nblk >> 3, r = nblk & 7, xcd = vb & 7, slot = vb >> 3;
+            const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+            const int grp = bid / (8 * tiles_n), rem = bid - grp * 8 * tiles_n;
+            const int gm = min(8, tiles_m - 8 * grp);
+            const int tn = rem / gm, tm = 8 * grp + rem - tn * gm;
+            m0 = tm * 128; n0 = tn * 128;
+            if (m0 < M) { ok = true; return; }
+        }
+    }
+    __device__ __forceinline__ void first(int vb0, int step_, int nblk_, int tm_, int tn_, int M_)
+    {
+        vb = vb0; step = step_; nblk = nblk_; tiles_m = tm_; tiles_n = tn_; M = M_; seek();
+    }
+    __device__ __forceinline__ void next() { vb += step; seek(); }
+};
+
 template <bool A_MC, bool B_NC>
-__global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
+__global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];      // 2 stages x (A hi|mid|lo, B hi|mid|lo)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -359,16 +383,6 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
     if (g.dyn_kind == 1) M = min(M, *g.dyn);
     if (g.dyn_kind == 2) K = min(K, *g.dyn);
     const int tiles_n = (g.N + 127) / 128, tiles_m = (g.M + 127) / 128;
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int grp = bid / (8 * tiles_n), rem = bid - grp * 8 * tiles_n;
-    const int gm = min(8, tiles_m - 8 * grp);
-    const int tn = rem / gm, tm = 8 * grp + rem - tn * gm;
-    const int m0 = tm * 128, n0 = tn * 128;
-    if (m0 >= M) return;                                  // uniform over the workgroup
     int kb = 0, ke = K;
     if (g.split_k > 1) {
         const int ktiles = (K + SBK - 1) / SBK, per = (ktiles + g.split_k - 1) / g.split_k;
@@ -377,6 +391,12 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
         if (kb >= ke) return;
     }
     const int nk = (ke - kb + SBK - 1) / SBK;
+    // PERSISTENT over tiles (gridDim.x = min(tiles, CUs)): the K-tile pipeline runs across tile boundaries, so a
+    // tile's first loads, split and dispatch hide behind the previous tile's MFMAs and only its C stores remain
+    // un-overlapped (one workgroup per CU paid ~9 us per tile for them before)
+    TileIter ti;
+    ti.first(blockIdx.x, gridDim.x, nblk, tiles_m, tiles_n, M);
+    if (!ti.ok) return;                                   // uniform over the workgroup
 
     if (producer) {
         // waves 4-7 stage the A operand, waves 8-11 the B operand (256 threads each, the staging map of the
@@ -384,35 +404,29 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
         const bool isb = wave >= 8;
         const int ptid = tid - (isb ? 512 : 256);
         float4 r[4];
-        if (!isb) {
-            FastSrc<A_MC> fs;
-            fs.init(g.A, g.lda, m0, M, kb, ke, ptid);
-            fs.load(r, 0);
-            s_split_store<A_MC>(dsm, r, ptid);
-            if (nk > 1) fs.load(r, 1);
+        auto run = [&](auto& fs, auto xc, const float* P, int ld, bool is_a, unsigned short* base) __attribute__((always_inline)) {
+            constexpr bool XC = decltype(xc)::value;
+            int kt = 0;                                   // load cursor: (ti, kt) = the next K tile to load
+            auto issue = [&]() __attribute__((always_inline)) {
+                if (kt == 0) fs.init(P, ld, is_a ? ti.m0 : ti.n0, is_a ? M : g.N, kb, ke, ptid);
+                fs.load(r, kt);
+                if (++kt == nk) { kt = 0; ti.next(); }
+            };
+            issue();
+            s_split_store<XC>(base, r, ptid);
+            bool nxt = ti.ok;
+            if (nxt) issue();
             __syncthreads();
-            for (int it = 0; it < nk; ++it) {
-                if (it + 1 < nk) {
-                    s_split_store<A_MC>(dsm + ((it + 1) & 1) * 6 * SPLANE, r, ptid);
-                    if (it + 2 < nk) fs.load(r, it + 2);
-                }
+            for (int G = 0; ; ++G) {                      // consumers work on K tile G of this workgroup's sequence
+                if (!nxt) { __syncthreads(); break; }
+                s_split_store<XC>(base + ((G + 1) & 1) * 6 * SPLANE, r, ptid);
+                nxt = ti.ok;
+                if (nxt) issue();
                 __syncthreads();
             }
-        } else {
-            FastSrc<B_NC> fs;
-            fs.init(g.B, g.ldb, n0, g.N, kb, ke, ptid);
-            fs.load(r, 0);
-            s_split_store<B_NC>(dsm + 3 * SPLANE, r, ptid);
-            if (nk > 1) fs.load(r, 1);
-            __syncthreads();
-            for (int it = 0; it < nk; ++it) {
-                if (it + 1 < nk) {
-                    s_split_store<B_NC>(dsm + ((it + 1) & 1) * 6 * SPLANE + 3 * SPLANE, r, ptid);
-                    if (it + 2 < nk) fs.load(r, it + 2);
-                }
-                __syncthreads();
-            }
-        }
+        };
+        if (!isb) { FastSrc<A_MC> fs; run(fs, std::integral_constant<bool, A_MC>{}, g.A, g.lda, true, dsm); }
+        else      { FastSrc<B_NC> fs; run(fs, std::integral_constant<bool, B_NC>{}, g.B, g.ldb, false, dsm + 3 * SPLANE); }
         return;
     }
 
@@ -422,56 +436,58 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g)
     int offa[2], offb[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) { offa[s] = sw_off(64 * wm + l31, 2 * s + h); offb[s] = 3 * SPLANE + sw_off(64 * wn + l31, 2 * s + h); }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __syncthreads();
-    for (int it = 0; it < nk; ++it) {
-        const unsigned short* st = dsm + (it & 1) * 6 * SPLANE;
-        bf16x8 a[2][2][3], b[2][2][3];          // [step][tile][plane]: all 24 fragments of the K tile in flight at once
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offa[s] + p * SPLANE + 32 * t * SLD));
-                    b[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offb[s] + p * SPLANE + 32 * t * SLD));
-                }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#define AVAE_PROD(pa, pb)                                                                                     \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][pa], b[s][j][pb], acc[i][j], 0, 0, 0);
-            AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) AVAE_PROD(0, 0)
-#undef AVAE_PROD
-        }
-        __syncthreads();
-    }
-
     const bool atomic = g.split_k > 1;
     const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
+    __syncthreads();
+    for (int G = 0; ti.ok; ti.next()) {
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + 64 * wn + 32 * j + l31;
-        if (col >= g.N) continue;
-        const float bv = add_bias ? g.bias[col] : 0.f;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                const float v = g.alpha * acc[i][j][r] + bv;
-                float* c = g.C + (size_t)row * g.ldc + col;
-                if (atomic) atomicAdd(c, v);
-                else if (g.accumulate) *c += v;
-                else *c = v;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int it = 0; it < nk; ++it, ++G) {
+            const unsigned short* st = dsm + (G & 1) * 6 * SPLANE;
+            bf16x8 a[2][2][3], b[2][2][3];          // [step][tile][plane]
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        a[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offa[s] + p * SPLANE + 32 * t * SLD));
+                        b[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offb[s] + p * SPLANE + 32 * t * SLD));
+                    }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#define AVAE_PROD(pa, pb)                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][pa], b[s][j][pb], acc[i][j], 0, 0, 0);
+                AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) AVAE_PROD(0, 0)
+#undef AVAE_PROD
+            }
+            __syncthreads();
+        }
+        const int m0 = ti.m0, n0 = ti.n0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + l31;
+            if (col >= g.N) continue;
+            const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= M) continue;
+                    const float v = g.alpha * acc[i][j][r] + bv;
+                    float* c = g.C + (size_t)row * g.ldc + col;
+                    if (atomic) atomicAdd(c, v);
+                    else if (g.accumulate) *c += v;
+                    else *c = v;
+                }
             }
         }
     }
@@ -482,12 +498,18 @@ static hipError_t launch_ws(hipStream_t st, dim3 grid, const GemmArgs& g)
 {
     constexpr int lds_bytes = 2 * 6 * SPLANE * 2;
     static bool attr_set = false;
+    static int ncu = 256;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32s_ws_kernel<A_MC, B_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32s_ws_kernel<A_MC, B_NC>), grid, dim3(768), lds_bytes, st, g);
+    const int tiles = (int)grid.x;
+    // one workgroup per CU walks its tiles; with split-K every (tile, slice) keeps its own workgroup
+    if (grid.z == 1 && tiles > ncu) grid.x = ncu / 8 * 8;
+    hipLaunchKernelGGL((gemm_f32s_ws_kernel<A_MC, B_NC>), grid, dim3(768), lds_bytes, st, g, tiles);
     return hipGetLastError();
 }
 
