@@ -6,7 +6,8 @@
 //     hi = rne(x),  mid = rne(x - hi),  lo = rne(x - hi - mid)          (both subtractions are exact)
 // so that x = hi + mid + lo up to 2^-27 |x|.  A product a*b is then accumulated in fp32 from the six partial
 // products whose weight is >= 2^-18:  lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  (each bf16 x bf16 product
-// is exact in fp32; the three dropped products are <= 2^-26 |a b| together).  The result carries the same kind
+// is exact in fp32; the three dropped products are <= 2^-23 |a b| in the worst case, ~2^-27 |a b| rms with zero
+// mean: below the 2^-24 rounding of the fp32 accumulation they would be added into).  The result carries the same kind
 // and size of error as an fp32 GEMM -- the fp32 accumulation -- and the parity tests hold it to the fp32
 // tolerances; it is not a reduced-precision mode.  Six 32-cycle MFMAs replace eight 64-cycle ones per 16-deep
 // K step: 2.67x the matrix-core rate of the exact-fp32 kernel (peak 2.5 PFLOP/s / 6 = 417 TFLOP/s fp32-equivalent).
