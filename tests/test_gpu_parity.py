@@ -589,3 +589,36 @@ def test_tf_checkpoint_files_roundtrip(tmp_path):
     m.train_step(ids, ids, keep_mask=keep, eps=eps)
     m2.train_step(ids, ids, keep_mask=keep, eps=eps)
     assert abs(m.losses()[2] - m2.losses()[2]) <= 1e-5 * abs(m.losses()[2])
+
+
+def test_split_bf16_mode_ragged_batch_at_bench_scale():
+    """ragged lengths at B=256, S=64, D=512, V=8192: the device-side row counts (dyn M / dyn K), the skipped tiles of
+    the persistent wave-specialised kernel and the buffer-bound predicates of the fast staging path, against the
+    exact-fp32 path on the same batch"""
+    import torch
+    from argsim_amd.model import VAE
+    kw = dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3, seed=0)
+    rng = np.random.default_rng(3)
+    lens = np.clip(np.round(rng.lognormal(np.log(24), 0.5, 256)), 2, 64).astype(int)
+    ids = np.ones((256, 64), np.int32)                      # eos padded
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(3, 8192, n)
+    keep = (rng.random((int(lens.max()), 256)) < 0.88).astype(np.uint8)
+    eps = rng.standard_normal((256, 128)).astype(np.float32)
+    res = {}
+    for dt in ('f32', 'f32s'):
+        m = VAE('train', dtype=dt, **kw)
+        m.step = 20000
+        z = m.encode(ids)
+        errt, lgen, lkld = m.eval(ids, ids)
+        m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+        res[dt] = (z, lgen, m.losses(), m.get_grads())
+        del m
+        torch.cuda.empty_cache()
+    assert res['f32'][1].shape == (int(lens.sum()) + 256,)
+    assert np.abs(res['f32'][0] - res['f32s'][0]).max() <= 2e-5
+    assert np.abs(res['f32'][1] - res['f32s'][1]).max() <= 1e-4
+    for a, b in zip(res['f32'][2], res['f32s'][2]):
+        assert abs(a - b) <= 2e-6 * abs(a)
+    bad = {k: rel_l2(res['f32s'][3][k], v) for k, v in res['f32'][3].items() if rel_l2(res['f32s'][3][k], v) > 1e-4}
+    assert not bad, bad
