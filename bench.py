@@ -44,7 +44,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(sample_b=32, steps=2):
+def cpu_baseline(sample_b=64, steps=6):       # ~10 s of host work at ~45 sentences/s
     import numpy as np
     import torch
     from argsim_amd import synth
