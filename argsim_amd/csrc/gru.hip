@@ -1051,6 +1051,151 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ backward, D = 512, four teams per CU
+// The LDS-weight form of the backward step (the forward's gru_fwd_team_kernel is its model): ONE workgroup of 16
+// waves owns a (job, 64-row block, 16-unit slice); its 1536 x 16 slice of R' (the B operand of dH_prev = dgh R)
+// lives in LDS in MFMA B-fragment order (96 KB, one ds_read_b128 per four MFMA steps) and is shared by FOUR teams
+// of 4 waves; every team runs an independent 16-row chain.  The register form above holds the slice in 96 VGPRs,
+// which caps it at two chains per CU; here four chains per CU keep twice the dgh bytes in flight per SIMD.  A
+// operand: the same hand-counted sc1 piece stream with a running-max sentinel check and a one-instruction probe
+// as the D = 512 path above, with a ring of TWO 24-register pieces (128-register budget at 4 waves per SIMD).
+// Encoder layers only (no dh0 tail).  Teams synchronise through monotonic LDS counters, never s_barrier.
+__global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
+{
+    constexpr int D = 512, HT = 32, NH = 4, PQ = 6, NB = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wl = lds;                                        // [wk 4][ks4 24][lane 64][4]      96 KB
+    float* part = Wl + 4 * 24 * 256;                        // [team 4][wk 4][256]             16 KB
+    float* red = part + kTeams * 4 * 256;                   // [4][16] bias-gradient sums
+    unsigned* sync = reinterpret_cast<unsigned*>(red + 64); // [team 4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = wave >> 2, wk = wave & 3;
+    const int n = lane & 15, kh = lane >> 4;
+    const int nrb = a.B / 64, chains = a.njobs * nrb;
+    const int cid = blockIdx.x % chains, ht = blockIdx.x / chains;
+    const int jb = cid / nrb, rblk = cid % nrb;
+    const GruJob& J = a.job[jb];
+    const int B = a.B, S = a.S;
+    const int row0 = rblk * 64 + team * 16;
+
+    // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
+    for (int blk = wave; blk < 96; blk += 16) {
+        const int wq = blk / 24, ks4 = blk % 24;
+        const float* rp = J.R + (size_t)(wq * 384 + 16 * ks4 + 4 * kh) * D + ht * 16 + n;
+        *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[D], rp[2 * D], rp[3 * D]);
+    }
+    if (tid < kTeams) sync[tid] = 0u;
+    if (tid < 64) red[tid] = 0.f;
+    const int tt = tid & 255, gn = tt & 15, gr = tt >> 4;
+    const int j = ht * 16 + gn;
+    const int len_a = J.reverse ? a.lens[row0 + n] : 0, len_g = J.reverse ? a.lens[row0 + gr] : 0;
+    const int len_p = J.reverse ? a.lens[row0 + 15] : 0;
+    const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
+    float* tpart = part + team * (4 * 256);
+    unsigned* tsync = sync + team;
+    unsigned epoch = 0;
+    {
+        const int tq = __builtin_amdgcn_readfirstlane(team);      // one arbitration order on all four SIMDs (see the forward)
+        if (tq == 0) __builtin_amdgcn_s_setprio(3);
+        else if (tq == 1) __builtin_amdgcn_s_setprio(2);
+        else if (tq == 2) __builtin_amdgcn_s_setprio(1);
+    }
+    const unsigned long long pa = (unsigned long long)J.dgh;
+    const i32x4 srd = {(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
+    const int grow = row0 + gr;
+    float sb_r = 0.f, sb_u = 0.f, sb_n = 0.f, sb_nr = 0.f;
+    int done = 0;
+    for (int p = a.p_end - 1; p >= a.p_begin; --p, ++done) {
+        const bool have_next = p + 1 < S;
+        const bool poll = done > 0;
+        // (1) exchange-independent loads of the gate phase
+        const size_t rix = (size_t)pos_map(p, len_g, J.reverse) * B + grow;
+        const float4 sv = *reinterpret_cast<const float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4);
+        const float s_hp = J.hp[rix * D + j];
+        const float s_do = J.dh_out ? J.dh_out[rix * a.ldh + j] : 0.f;
+        // (2)+(3) A operand = dgh_{p+1} of the team's 16 rows, this wave's K quarter, in four 96-float pieces
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        if (have_next) {
+            const unsigned voff = (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * 384) * 4) + 16 * kh;
+            u32x4 hv[NB][PQ];
+            f32x4 acc[2];
+            auto pass = [&]() __attribute__((always_inline)) -> bool {
+                unsigned mx = 0u;
+                asm_issue6<0>(hv[0], voff, srd);
+#pragma unroll
+                for (int st = 0; st < NH; ++st) {
+                    if (st + 1 < NH) {
+                        if (st + 1 == 1) asm_issue6<384>(hv[1], voff, srd);
+                        if (st + 1 == 2) asm_issue6<768>(hv[0], voff, srd);
+                        if (st + 1 == 3) asm_issue6<1152>(hv[1], voff, srd);
+                        asm_wait6<6>(hv[st % NB]);
+                    } else {
+                        asm_wait6<0>(hv[st % NB]);
+                    }
+                    if (st == 0) { acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q)
+                        mx = max(max(mx, max(hv[st % NB][q].x, hv[st % NB][q].y)), max(hv[st % NB][q].z, hv[st % NB][q].w));
+                    asm volatile("" : "+v"(mx));
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 24 + st * 6 + q) * 64 + lane) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][q][e]), b[e], acc[e & 1], 0, 0, 0);
+                    }
+                }
+                sum = acc[0] + acc[1];
+                return __any(mx == kSentinel);
+            };
+            SpinGuard sg;
+            for (;;) {
+                if (poll) {
+                    // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
+                    const float* pp = J.dgh + ((size_t)pos_map(p + 1, len_p, J.reverse) * B + row0 + 15) * a.ldg + (lane & 31) * 48 + 47;
+                    while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                }
+                const bool bad = pass();
+                if (!poll || !bad || sg.expired(a.err)) break;
+            }
+        }
+        // every wave of the team has finished READING the previous step's partial sums, then publish this step's
+        if (done > 0) { epoch += 4; team_barrier(tsync, epoch); }
+        *reinterpret_cast<f32x4*>(tpart + wk * 256 + lane * 4) = sum;
+        epoch += 4; team_barrier(tsync, epoch);
+        // (4) gate derivatives: the team's 256 threads, one (row, unit) each; exchanged stores first
+        {
+            const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
+            float carried = (tpart[pidx] + tpart[256 + pidx]) + (tpart[512 + pidx] + tpart[768 + pidx]);
+            float* carryp = J.carry + (size_t)grow * D + j;
+            if (have_next) carried += *carryp;
+            const float dH = carried + s_do;
+            const float r = sv.x, u = sv.y, nn = sv.z;
+            const float dn = dH * (1.f - u) * (1.f - nn * nn);
+            const float du = dH * (s_hp - nn) * u * (1.f - u);
+            const float dr = dn * sv.w * r * (1.f - r);
+            float* dgh = J.dgh + rix * a.ldg + ht * 48 + gn * 3;
+            if (fast) { dgh[0] = dr; dgh[1] = du; dgh[2] = dn * r; }
+            else { store4_sc1(dgh, dr); store4_sc1(dgh + 1, du); store4_sc1(dgh + 2, dn * r); }
+            *carryp = dH * u;
+            float* dgi = J.dgi + rix * a.ldg + ht * 48 + gn * 3;
+            dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
+            sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r;
+        }
+    }
+    // bias gradients: all 64 rows of the workgroup into LDS, then one atomic per (gate, unit)
+    if (J.dbW || J.dbR) {
+        atomicAdd(&red[gn], sb_r); atomicAdd(&red[16 + gn], sb_u); atomicAdd(&red[32 + gn], sb_n); atomicAdd(&red[48 + gn], sb_nr);
+        __syncthreads();
+        if (tid < 48) {
+            const int gate = tid >> 4, u = tid & 15;
+            if (J.dbW) atomicAdd(J.dbW + ht * 48 + u * 3 + gate, red[gate * 16 + u]);
+            if (J.dbR) atomicAdd(J.dbR + ht * 48 + u * 3 + gate, red[(gate == 2 ? 3 : gate) * 16 + u]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ launchers
 constexpr int kGruSyncWords = 64 + 64 + 1536;   // (spare) | detection counters | XCD ids (njobs*G*HT)
 bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 512; }
@@ -1159,6 +1304,19 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
         e = prepare_exchange(st, a, false); if (e != hipSuccess) return e;
+        // D = 512, two directions without a dh0 tail (the encoder layers), B = 64 x (1..4), whole sequence in one launch
+        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !a.ablate && a.item_pipeline == 2 &&
+            a.p_begin == 0 && a.p_end == a.S && !a.job[0].dh0 && !a.job[1].dh0) {
+            const int lds_bytes = (4 * 24 * 256 + kTeams * 4 * 256 + 64) * 4 + 64;
+            static bool attr_set = false;
+            if (!attr_set) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gru_bwd_team_kernel, dim3(a.njobs * (a.B / 64) * 32), dim3(1024), lds_bytes, st, a);
+            return hipGetLastError();
+        }
         return launch<false>(st, a, grid);
     }
     // one launch per step (descending); the dh0 tail (p = -1) is its own launch

@@ -622,3 +622,34 @@ def test_split_bf16_mode_ragged_batch_at_bench_scale():
         assert abs(a - b) <= 2e-6 * abs(a)
     bad = {k: rel_l2(res['f32s'][3][k], v) for k, v in res['f32'][3].items() if rel_l2(res['f32s'][3][k], v) > 1e-4}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_bench_scale_backward_persistent_equals_stepwise(ragged):
+    """B=256, S=64, D=512: gradients of the persistent GRU kernels (LDS-weight team kernels for the encoder, register
+    form for the decoder) against one launch per step, on a FULL and on a ragged batch -- same arithmetic, so the
+    difference is float-atomic ordering only"""
+    import torch
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    kw = dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3, seed=0)
+    rng = np.random.default_rng(5)
+    ids = synth.batch(256, 64, 8192, seed=1)
+    if ragged:
+        lens = np.clip(np.round(rng.lognormal(np.log(24), 0.5, 256)), 2, 64).astype(int)
+        lens[0] = 64
+        for b, n in enumerate(lens):
+            ids[b, n:] = 1
+    keep = (rng.random((64, 256)) < 0.88).astype(np.uint8)
+    eps = rng.standard_normal((256, 128)).astype(np.float32)
+    m = VAE('train', **kw)
+    m.step = 20000
+    out = {}
+    for persistent in (1, 0):
+        m.set_option('persistent', persistent)
+        m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+        out[persistent] = (m.losses(), m.get_grads())
+    for x, y in zip(out[1][0], out[0][0]):              # (the two scalar loss sums are float atomics)
+        assert abs(x - y) <= 2e-6 * abs(y)
+    bad = {k: rel_l2(out[1][1][k], v) for k, v in out[0][1].items() if rel_l2(out[1][1][k], v) > 2e-6}
+    assert not bad, bad
