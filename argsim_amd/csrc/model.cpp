@@ -256,8 +256,17 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
             const int main_rows = main_mt * 128, tail_rows = M - main_rows;
             AV_TRY(gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, main_rows, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind));
             // rows beyond the device-side row count hold unread garbage either way: the tail keeps the static bound
-            return gemm_raw(h, a_mc, b_nc, A + (size_t)main_rows * lda, lda, Bm, ldb, C + (size_t)main_rows * ldc, ldc,
-                            tail_rows, N, K, alpha, bias, accumulate, 1, nullptr, 0, 1);
+            const float* At = A + (size_t)main_rows * lda; float* Ct = C + (size_t)main_rows * ldc;
+            if (allow_atomic && !accumulate && ldc == N && K >= 1024) {
+                // backward only: a few rows x a long K (dho: 256 rows x K = 8192 took 0.2 ms on 32 thin tiles):
+                // K split over ~768 workgroups of full tiles with float atomics instead
+                const int s = std::min(768 / (((tail_rows + 127) / 128) * nt), K / 128);
+                if (s >= 2) {
+                    AV_CHECK(hipMemsetAsync(Ct, 0, sizeof(float) * (size_t)tail_rows * N, h->stream));
+                    return gemm_raw(h, a_mc, b_nc, At, lda, Bm, ldb, Ct, ldc, tail_rows, N, K, alpha, bias, 0, s, nullptr, 0);
+                }
+            }
+            return gemm_raw(h, a_mc, b_nc, At, lda, Bm, ldb, Ct, ldc, tail_rows, N, K, alpha, bias, accumulate, 1, nullptr, 0, 1);
         }
     }
     return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind);
@@ -418,14 +427,14 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_CHECK(hipMemsetAsync(G, 0, sizeof(float) * h->numel, st));
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
-    AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1));
+    AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1, true));
     // (V x D output = 256 tiles: one workgroup per CU cannot overlap its own staging; K = N rows split 3 ways fills
     //  three workgroups per CU; G was zero-filled above and the gather part is scatter-added at the end)
     AV_TRY(gemm(h, true, true, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, nullptr, 0, grad_split(V, D, rt), w.ntok, 2));
     // out affine
     AV_TRY(gemm_tn_grad(h, w.hc, D, w.dho, D, G + h->oKout, D, D, D, rt, 1.f, w.ntok));
     AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));
-    AV_TRY(gemm(h, false, false, w.dho, D, P + h->oKout, D, w.dhc, D, rt, D, D, 1.f, nullptr, 0, 0, w.ntok, 1));
+    AV_TRY(gemm(h, false, false, w.dho, D, P + h->oKout, D, w.dhc, D, rt, D, D, 1.f, nullptr, 0, 0, w.ntok, 1, true));
     fire_hook(h, 0);
     AV_CHECK(rows_expand(st, w.dhd[0], w.dhc, w.rank, rt, D));
 
@@ -448,7 +457,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt));
         AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
         float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
-        AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D));
+        AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
         fire_hook(h, 1 + (L - 1 - i));
     }
@@ -493,7 +502,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         for (int d = 0; d < 2; ++d)
             AV_TRY(gemm_tn_grad(h, w.dgh_e + d * 3 * D, 6 * D, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs));
         float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
-        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D));
+        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
         fire_hook(h, 2 + L + (L - 1 - i));
     }
