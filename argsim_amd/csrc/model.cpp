@@ -744,6 +744,20 @@ int avae_timing_collect(avae_handle h, double* out)
     h->stamps_used = 0;
     return 0;
 }
+// diagnostic: per-launch (class, ms, FLOPs) triples of the stamps recorded since timing was switched on, in launch
+// order (does not reset them); returns the number of stamps through *n
+int avae_debug_timing(avae_handle h, double* out, int max_n, int* n)
+{
+    if (!h || !out || !n) return 1;
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    *n = (int)std::min<size_t>(h->stamps_used, (size_t)max_n);
+    for (int i = 0; i < *n; ++i) {
+        float ms = 0.f;
+        AV_CHECK(hipEventElapsedTime(&ms, h->stamps[i].a, h->stamps[i].b));
+        out[3 * i] = h->stamps[i].cls; out[3 * i + 1] = ms; out[3 * i + 2] = h->stamps[i].flops;
+    }
+    return 0;
+}
 // diagnostic: reads and clears the 32 GRU phase-stamp words (option gru_ablate bit 32)
 int avae_debug_stamps(avae_handle h, unsigned long long* out)
 {

@@ -52,6 +52,7 @@ SIGNATURES = {
     'avae_set_option': (C.c_int, [_P, C.c_char_p, C.c_int]),
     'avae_debug_gemm': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P] + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int]),
     'avae_timing_collect': (C.c_int, [_P, C.POINTER(C.c_double)]),
+    'avae_debug_timing': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     'avae_debug_stamps': (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     'avae_bucket_count': (C.c_int, [_P]),
     'avae_bucket_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
