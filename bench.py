@@ -102,6 +102,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == A.gpus, "launch with torch.distributed.run --nproc-per-node %d" % A.gpus
+    if os.environ.get('AVAE_FORCE_DEVICE'):          # test hook: several ranks on one GPU (with AVAE_DIST_BACKEND=gloo)
+        local = int(os.environ['AVAE_FORCE_DEVICE'])
     torch.cuda.set_device(local)
     dp = None
     model = VAE('train', device=local, seed=0, dtype=A.dtype, **CFG)
@@ -110,7 +112,11 @@ def main():
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+            backend = os.environ.get('AVAE_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; gloo only for the one-GPU rehearsal
+            if backend == 'nccl':
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
         dp = DataParallel(model)
         dp.broadcast_params(model.state)
     if A.stepwise:
