@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBf16Args g)
     const int tiles_n = (g.N + 127) / 128;
     int bid = blockIdx.x;
     {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        const int nblk = ((M + 127) / 128) * tiles_n;       // effective tiles (device-side row count), <= gridDim.x
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        if (slot >= q + (xcd < r ? 1 : 0)) return;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;

@@ -105,11 +105,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give each
     // XCD a contiguous run of tiles; tiles advance along N fastest so a run shares A panels.
+    // The runs are cut over the EFFECTIVE tile count (device-side row count of a ragged batch): cut over the grid,
+    // the XCDs whose runs lie beyond the real rows would idle while the others carry the whole GEMM.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
+    const int nblk = ((M + BM - 1) / BM) * tiles_n;          // <= gridDim.x
     int bid = blockIdx.x;
     {
         int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        if (slot >= q + (xcd < r ? 1 : 0)) return;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;

@@ -217,16 +217,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
     if (g.dyn_kind == 2) K = min(K, *g.dyn);
 
     // XCD-aware tile order (as gemm_f32): blocks b, b+8, .. share an XCD; each XCD gets a contiguous run of tiles
+    // (runs cut over the EFFECTIVE tile count -- the device-side row count of a ragged batch -- so that no XCD idles)
     const int tiles_n = (g.N + 127) / 128;
+    const int tiles_m = (M + 127) / 128;
     int bid = blockIdx.x;
     {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        const int nblk = tiles_m * tiles_n, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        if (slot >= q + (xcd < r ? 1 : 0)) return;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     // grouped order inside the run: 8 row panels x all column panels, rows fastest, so that the ~64 tiles an XCD
     // works on at one time form an 8 x 8 block: 16 operand panels per K step instead of 3 + all of B
     // (the exact-fp32 kernel needs a quarter of this kernel's operand bandwidth and gets away without)
-    const int tiles_m = (g.M + 127) / 128;
     const int grp = bid / (8 * tiles_n), rem = bid - grp * 8 * tiles_n;
     const int gm = min(8, tiles_m - 8 * grp);
     const int tn = rem / gm, tm = 8 * grp + rem - tn * gm;
@@ -383,7 +385,8 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nb
     int M = g.M, K = g.K;
     if (g.dyn_kind == 1) M = min(M, *g.dyn);
     if (g.dyn_kind == 2) K = min(K, *g.dyn);
-    const int tiles_n = (g.N + 127) / 128, tiles_m = (g.M + 127) / 128;
+    const int tiles_n = (g.N + 127) / 128, tiles_m = (M + 127) / 128;       // effective row tiles (ragged batches)
+    nblk = min(nblk, tiles_m * tiles_n);
     int kb = 0, ke = K;
     if (g.split_k > 1) {
         const int ktiles = (K + SBK - 1) / SBK, per = (ktiles + g.split_k - 1) / g.split_k;

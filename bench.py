@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--no-timing', action='store_true', help="skip the per-kernel HIP-event stamps (roofline leg)")
     ap.add_argument('--batch', type=int, default=B, help="rows per GPU (default: BASELINE configs[1]; 1024 = configs[2]/[3] per-GPU load)")
     ap.add_argument('--seq', type=int, default=S, help="sequence length (default 64; 128 = configs[2])")
+    ap.add_argument('--ragged', action='store_true', help="RAGGED synthetic set (LogNormal lengths, eos padded) instead of FULL; not the headline")
     ap.add_argument('--no-alt', action='store_true', help="skip the extra f32s leg (same workload with the split-bf16 fp32 GEMMs)")
     ap.add_argument('--gru-stagger', type=int, default=0)
     ap.add_argument('--gru-item', type=int, default=-1, help="forward GRU kernel: 0 generic, 1 item pipeline, 2 four-team LDS-weight kernel")
@@ -90,7 +91,7 @@ def main():
     ap.add_argument('--gru-ablate', type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument('--stepwise', action='store_true', help="one GRU launch per time step instead of the persistent kernels")
     A = ap.parse_args()
-    headline = (A.batch, A.seq) == (B, S)
+    headline = (A.batch, A.seq) == (B, S) and not A.ragged
     B, S = A.batch, A.seq
 
     import torch
@@ -129,8 +130,11 @@ def main():
     if A.gru_ablate:
         model.set_option('gru_ablate', A.gru_ablate)
     model.step = 20000                                  # anneal = tanh(2): the KL backward is live
-    ids = torch.as_tensor(synth.batch(B, S, CFG['dim_tgt'], seed=rank)).to(model.device)   # FULL batch, resident in HBM
+    ids_np = synth.batch(B, S, CFG['dim_tgt'], ragged=A.ragged, seed=rank)
+    ids = torch.as_tensor(ids_np).to(model.device)      # FULL batch (default), resident in HBM
     n_glob, b_glob = float(world * B * (S + 1)), float(world * B)
+    if A.ragged:                                        # tokens of the global batch (same length law on every rank; exact for world 1)
+        n_glob = float(world * int((ids_np != 1).sum() + B))
 
     def one(i):
         if dp:
@@ -177,7 +181,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f32s": "f32 (GEMM operands split into 3 x bf16 in registers, 6 partial products, f32 accumulate)",
                       "bf16": "bf16 GEMM operands, f32 accumulate/recurrence/state/Adam"}[A.dtype], "data": "synthetic",
-            "config": {"workload": ("" if headline else "NOT the headline workload (batch %d x seq %d per GPU) -- " % (B, S)) +
+            "config": {"workload": ("" if headline else "NOT the headline workload (batch %d x seq %d per GPU%s) -- " % (B, S, ", RAGGED lengths" if A.ragged else "")) +
                                    "BASELINE configs[1]: 1xMI355X %s, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
                                    "FULL synthetic Zipf batches, dim_emb 512, 3 layers, step 20000"
                                    % {"f32": "fp32", "f32s": "fp32 (split-bf16 MFMA GEMMs, fp32-accurate)",
