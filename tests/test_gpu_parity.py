@@ -29,7 +29,8 @@ def _vae(cfg, P, **kw):
 
 
 @pytest.mark.parametrize("a_mc,b_nc", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 52), (4, 8, 16), (333, 260, 132), (1000, 512, 96)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 52), (4, 8, 16), (333, 260, 132), (1000, 512, 96),
+                                   (333, 256, 2048), (384, 128, 3072), (1280, 640, 1600)])     # buffer-load staging path
 def test_gemm(a_mc, b_nc, M, N, K):
     import torch
     from argsim_amd import lib
@@ -465,7 +466,10 @@ def test_bf16_mode_tracks_the_oracle(name):
 
 # ---------------------------------------------------------------- fp32 on the bf16 matrix cores (compute_dtype 2)
 @pytest.mark.parametrize("a_mc,b_nc", [(0, 0), (0, 1), (1, 1), (1, 0)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 52), (4, 8, 16), (333, 260, 132), (1000, 512, 96), (256, 384, 4100)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 52), (4, 8, 16), (333, 260, 132), (1000, 512, 96), (256, 384, 4100),
+                                   # long K, tile-aligned where the layout needs it: the buffer-load staging path and the
+                                   # persistent wave-specialised kernel (ragged M through num_records, 300+ tiles per launch)
+                                   (333, 256, 2048), (1000, 512, 1536), (384, 128, 3072), (4224, 1280, 1600)])
 def test_gemm_split_bf16_is_fp32_accurate(a_mc, b_nc, M, N, K):
     """the 3 x bf16 split GEMM (6 partial products, fp32 accumulate) against float64 products of the SAME fp32
     operands, at the tolerance of the exact-fp32 kernel's test (2e-5 of the result scale), on wide-range data"""
