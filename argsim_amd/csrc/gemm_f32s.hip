@@ -347,11 +347,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
 // ---------------------------------------------------------------- wave-specialised form (fast-path shapes)
 // One 768-thread workgroup per CU: waves 0-3 ("consumers", one per SIMD) only read fragments and issue MFMAs,
 // waves 4-11 ("producers", two per SIMD) only load, split and store the NEXT K tile into the other half of a
-// double-buffered LDS image (2 x 48 KB).  One s_barrier per K tile.  In the phase-structured kernel above each
-// wave alternates between ~1900 cycles of vector work and 1536 cycles of MFMA and three workgroups per CU do not
-// line up well enough to keep the matrix pipe busy (60 % measured); here the pipe's wave never leaves the MFMA
-// stream and the split runs beside it on the same SIMD (vector issue: 48 x 8 cycles of MFMA + ~180 x 4 cycles of
-// split per 1536-cycle K tile).
+// double-buffered LDS image (2 x 48 KB).  One s_barrier per K tile, persistent over the workgroup's tiles.  In the
+// phase-structured kernel above each wave alternates between ~1900 cycles of vector work and 1536 cycles of MFMA
+// and three workgroups per CU keep the matrix pipe ~60 % busy; here the MFMA wave never leaves its stream.  What
+// was measured: the producers finish early and wait at the barrier, but the consumer's 48 MFMAs
+// take ~2400 cycles instead of 1536 -- the producers' vector instructions on the same SIMD cost the MFMA stream
+// their issue time -- so this form wins ~5 % on long-K shapes and loses on short K, where one workgroup per CU
+// leaves a tile's 64 KB C store un-overlapped.
+
 // the tiles one workgroup works through: virtual block ids blockIdx.x, + gridDim.x, ... through the XCD-aware grouped
 // order; tiles beyond the device-side row count are skipped (both roles walk the same sequence)
 struct TileIter {
