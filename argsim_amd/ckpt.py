@@ -38,10 +38,29 @@ def state_dict(vae, slots=True):
     return out
 
 
-def load_state_dict(vae, sd, strict=True):
+def audit(vae, sd):
+    """(missing, unexpected, misshapen) of a native-named state dict against the model's variable table"""
+    known = set(vae.names) | {'global_step'}
+    known |= {'train/%s/%s' % (k, s) for k in vae.names for s in ('Adam', 'Adam_1')} | {'train/beta1_power', 'train/beta2_power'}
     missing = [k for k in vae.names if k not in sd]
-    if missing and strict:
-        raise KeyError("checkpoint lacks variables: %s" % missing[:5])
+    unexpected = sorted(k for k in sd if k not in known)
+    misshapen = []
+    for k in sd:
+        base = k[len('train/'):].rsplit('/', 1)[0] if k.startswith('train/') and k.count('/') > 1 else k
+        if base in vae.shapes and tuple(np.shape(sd[k])) != tuple(vae.shapes[base]):
+            misshapen.append((k, tuple(np.shape(sd[k])), tuple(vae.shapes[base])))
+    return missing, unexpected, misshapen
+
+
+def load_state_dict(vae, sd, strict=True):
+    """name-based restore.  Shapes are checked against the model BEFORE anything is written; strict also refuses
+    missing model variables and keys the model does not know (a partial 'infer' restore passes strict=False)."""
+    missing, unexpected, misshapen = audit(vae, sd)
+    if misshapen:
+        raise ValueError("checkpoint tensors do not fit the model (name, found, expected): %s" % misshapen[:5])
+    if strict and (missing or unexpected):
+        raise KeyError("checkpoint does not match the model: missing %s%s; unexpected %s%s"
+                       % (missing[:5], ' ...' if len(missing) > 5 else '', unexpected[:5], ' ...' if len(unexpected) > 5 else ''))
     for k in vae.names:
         if k in sd:
             vae.set_tensor(k, sd[k], PARAM)
@@ -186,9 +205,17 @@ def save_tf(vae, prefix, slots=True):
 
 
 def restore_tf(vae, prefix, strict=True):
-    """saver.restore(sess, prefix) from TF V2 checkpoint files (src/train.py:93-94, eval_embed_reason.py:24-27)"""
+    """saver.restore(sess, prefix) from TF V2 checkpoint files (src/train.py:93-94, eval_embed_reason.py:24-27).
+    The CudnnGRU leaf names and gate order are quoted from memory of tf.contrib.cudnn_rnn (parity unpinned: no
+    TensorFlow and no reference checkpoint here), so a mismatch must be loud: a file whose GRU tensors are absent
+    or shaped differently raises with the offending names instead of loading the rest."""
     from . import tf_bundle
     raw = tf_bundle.read_bundle(prefix)
+    want = [k for k in to_tf_names({n: np.zeros(vae.shapes[n], np.float32) for n in vae.names})]
+    absent = [k for k in want if k not in raw]
+    if absent:
+        raise KeyError("TF checkpoint %r lacks %d of the %d tensors this model restores, e.g. %s; it holds e.g. %s"
+                       % (prefix, len(absent), len(want), absent[:3], sorted(raw)[:3]))
     sd = from_tf_names({k: v for k, v in raw.items() if not k.startswith('train/')}, vae.names)
     groups = _opaque_groups(vae.names)
     in_gru = {b + n for bases in groups.values() for b in bases for n in ('W', 'R', 'bW', 'bR')}

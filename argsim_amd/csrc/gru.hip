@@ -34,6 +34,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kSentinel = 0xFFFFFFFFu;
 
+// An exchanged value must never alias the "not yet written" pattern: a NaN that reaches the gate math with every
+// payload bit set (e.g. from a poisoned parameter) would otherwise make every consumer spin until its 2 s bound.
+// Such a value is stored as the canonical quiet NaN instead: still a NaN, never the sentinel.
+__device__ __forceinline__ float not_sentinel(float v)
+{
+    return __float_as_uint(v) == kSentinel ? __uint_as_float(0x7FC00000u) : v;
+}
 __device__ __forceinline__ int pos_map(int p, int len, int reverse) { return (reverse && p < len) ? (len - 1 - p) : p; }
 // sigmoid / tanh on v_exp_f32 + v_rcp_f32 (each <= 1 ulp): absolute error ~1e-7, far inside the
 // fp32 parity tolerances, at a fraction of the libm cost that sat on the per-step critical path
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     const int B = a.B;
     const int row_beg = g * a.rows_per_group;
     const int row_end = min(B, row_beg + a.rows_per_group);
-    const int ab = a.ablate;
+    const int ab = STAMPS ? a.ablate : 0;                      // timing experiments exist in the diagnostic instantiation only
     const bool one_sc = row_end - row_beg <= 32;               // single super-chunk: lengths stay in registers
 
     // weights -> registers, MFMA B-operand order: B[k][n] = R'[ht*48 + gate*16 + n][k]
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                 const float hnew = (1.f - u) * nn + u * hprev;
                 // (6) exchanged store first
                 float* hdst = J.hs + ((size_t)gpos[c] * B + row) * a.ldh + j;
-                if (fast) *hdst = hnew; else store4_sc1(hdst, hnew);
+                if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
                 o_r[c] = r; o_u[c] = u; o_n[c] = nn; o_hn[c] = gh[2]; o_hp[c] = hprev;
             }
             AVAE_STAMP(4);
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
             const float hnew = (1.f - u) * nn + u * hprev;
             const size_t rix = (size_t)gpos * B + grow;
             float* hdst = J.hs + rix * a.ldh + j;
-            if (fast) *hdst = hnew; else store4_sc1(hdst, hnew);
+            if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
             if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r, u, nn, gh[2]);
             if (J.hp) J.hp[rix * D + j] = hprev;
         }
@@ -629,8 +636,49 @@ __device__ __forceinline__ void team_barrier(unsigned* word, unsigned target)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+
+// MFMA turnstile of the team kernels.  Four chains share a CU's four matrix pipes and every chain's K split puts one
+// wave on each SIMD; left to the hardware arbiter the four SIMDs serve the teams in different orders and a team's
+// partial sums wait for the slowest SIMD at the team barrier (~2 us per step).  With the turnstile exactly one team
+// issues MFMAs at a time, on all four SIMDs together: the window of a team is its 96 MFMAs per wave back to back,
+// the other teams' exchange waits, operand loads and gate math run beside it.
+//   words: [0] completed wave-windows  [1] next ticket  [2..5] per-team ready count  [6..9] per-team ticket (+1)
+struct Turnstile {
+    unsigned* w; int mode; unsigned last = 0;
+    __device__ __forceinline__ void enter(int team, unsigned slot)
+    {
+        if (mode == 0) return;
+        unsigned first;
+        if (mode == 1) first = 4u * slot;                           // cyclic: slot = 4 * step + team
+        else {
+            unsigned old = 0;
+            if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(w + 2 + team, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if ((old & 3u) == 3u && (threadIdx.x & 63) == 0) {       // the team's last wave draws the ticket
+                const unsigned t = __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(w + 6 + team, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            unsigned tk;
+            while ((tk = __hip_atomic_load(w + 6 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == last) __builtin_amdgcn_s_sleep(1);
+            last = tk;
+            first = 4u * (tk - 1u);
+        }
+        while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void leave()
+    {
+        if (mode == 0) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <bool DIAG>
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
+    const int ab = DIAG ? a.ablate : 0;                     // timing experiments / stamps: diagnostic instantiation only
     constexpr int D = 512, HT = 32, WK = 128;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                                        // [wk 4][gate 3][q 8][lane 64][4]   96 KB
@@ -657,7 +705,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         const float4 v = *reinterpret_cast<const float4*>(J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 16 * q + 4 * kh);
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = v;
     }
-    if (tid < 2 * kTeams) sync[tid] = 0u;                   // [0..3] team barrier counters, [4..7] exchange-ready epochs
+    if (tid < 2 * kTeams + 10) sync[tid] = 0u;              // [0..3] team barrier counters, [4..7] exchange-ready epochs, [8..17] turnstile
     const int tt = tid & 255;                               // thread inside the team
     const int gn = tt & 15, gr = tt >> 4;
     const int j = ht * 16 + gn;
@@ -672,25 +720,26 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     float* thps = hps + team * 256;
     unsigned* tsync = sync + team;
     unsigned epoch = 0;
+    Turnstile ts{sync + 2 * kTeams, a.turn};
     // de-phase the four chains: identical chains started together stay in lock step and collide on the matrix
     // pipe; an initial offset of a fraction of a step per team persists (equal periods)
     for (int i = 0; i < team * a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     // one consistent arbitration order on all four SIMDs: a team's K-split partners sit on different SIMDs and
     // meet at the team barrier, so if every SIMD serves the teams in the same order the partners finish together
     // (otherwise the barrier pays the arbitration skew, measured at 2-3 us per step)
-    if (a.ablate & 256) { } else {
+    if (ab & 256) { } else {
         const int tq = __builtin_amdgcn_readfirstlane(team);
         if (tq == 0) __builtin_amdgcn_s_setprio(3);
         else if (tq == 1) __builtin_amdgcn_s_setprio(2);
         else if (tq == 2) __builtin_amdgcn_s_setprio(1);
     }
 
-    const bool stamp = (a.ablate & 128) != 0;                  // diagnostic phase stamps (never in timed runs)
+    const bool stamp = (ab & 128) != 0;                        // diagnostic phase stamps (never in timed runs)
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TSTAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
     for (int p = a.p_begin; p < a.p_end; ++p) {
         TSTAMP(5);
-        const bool poll = p > a.p_begin && !(a.ablate & 16);      // ablate 16: timing experiment, wrong results
+        const bool poll = p > a.p_begin && !(ab & 16);            // ablate 16: timing experiment, wrong results
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
@@ -730,6 +779,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
         TSTAMP(0);
+        ts.enter(team, 4u * (unsigned)(p - a.p_begin) + (unsigned)team);
+        TSTAMP(4);
         // (3) MFMAs, B fragments from LDS
         f32x4 acc[3];
 #pragma unroll
@@ -746,6 +797,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 for (int gate = 0; gate < 3; ++gate)
                     acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ra[q][e]), b[gate][e], acc[gate], 0, 0, 0);
         }
+        ts.leave();
         TSTAMP(1);
         // every wave of the team has finished READING the previous step's partial sums (second team barrier
         // of that step, taken here so that it costs nothing), then publish this step's
@@ -773,7 +825,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             const float hnew = (1.f - u) * nn + u * hprev;
             const size_t rix = (size_t)gpos * B + grow;
             float* hdst = J.hs + rix * a.ldh + j;
-            if (fast) *hdst = hnew; else store4_sc1(hdst, hnew);
+            if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
             if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r, u, nn, gh[2]);
             if (J.hp) J.hp[rix * D + j] = hprev;
         }
@@ -809,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     const int B = a.B, S = a.S;
     const int row_beg = g * a.rows_per_group;
     const int row_end = min(B, row_beg + a.rows_per_group);
-    const int ab = a.ablate;
+    const int ab = STAMPS ? a.ablate : 0;
     const bool one_sc = row_end - row_beg <= 32;
 
     // B operand: B[k = c'][n] = R'[c'][ht*16 + n]
@@ -1010,8 +1062,9 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                 const float du = dH * (s_hp[c] - nn) * u * (1.f - u);
                 const float dr = dn * s_hn[c] * r * (1.f - r);
                 float* dgh = J.dgh + (size_t)rix[c] * a.ldg + ht * 48 + gn * 3;
-                if (fast) { dgh[0] = dr; dgh[1] = du; dgh[2] = dn * r; }                          // exchanged
-                else { store4_sc1(dgh, dr); store4_sc1(dgh + 1, du); store4_sc1(dgh + 2, dn * r); }
+                const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r);
+                if (fast) { dgh[0] = x0; dgh[1] = x1; dgh[2] = x2; }                              // exchanged
+                else { store4_sc1(dgh, x0); store4_sc1(dgh + 1, x1); store4_sc1(dgh + 2, x2); }
                 o_dr[c] = dr; o_du[c] = du; o_dn[c] = dn; o_car[c] = dH * u;
                 sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r;
             }
@@ -1060,9 +1113,10 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 // operand: the same hand-counted sc1 piece stream with a running-max sentinel check and a one-instruction probe
 // as the D = 512 path above, with a ring of TWO 24-register pieces (128-register budget at 4 waves per SIMD).
 // Encoder layers only (no dh0 tail).  Teams synchronise through monotonic LDS counters, never s_barrier.
+template <int NB>
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
-    constexpr int D = 512, HT = 32, NH = 4, PQ = 6, NB = 2;
+    constexpr int D = 512, HT = 32, NH = 4, PQ = 6;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                                        // [wk 4][ks4 24][lane 64][4]      96 KB
     float* part = Wl + 4 * 24 * 256;                        // [team 4][wk 4][256]             16 KB
@@ -1085,7 +1139,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         const float* rp = J.R + (size_t)(wq * 384 + 16 * ks4 + 4 * kh) * D + ht * 16 + n;
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[D], rp[2 * D], rp[3 * D]);
     }
-    if (tid < kTeams) sync[tid] = 0u;
+    if (tid < kTeams + 10) sync[tid] = 0u;                  // [0..3] team barrier counters, [4..13] turnstile
     if (tid < 64) red[tid] = 0.f;
     const int tt = tid & 255, gn = tt & 15, gr = tt >> 4;
     const int j = ht * 16 + gn;
@@ -1095,6 +1149,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     float* tpart = part + team * (4 * 256);
     unsigned* tsync = sync + team;
     unsigned epoch = 0;
+    Turnstile ts{sync + kTeams, a.turn};
     {
         const int tq = __builtin_amdgcn_readfirstlane(team);      // one arbitration order on all four SIMDs (see the forward)
         if (tq == 0) __builtin_amdgcn_s_setprio(3);
@@ -1120,19 +1175,28 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             const unsigned voff = (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * 384) * 4) + 16 * kh;
             u32x4 hv[NB][PQ];
             f32x4 acc[2];
+            auto issue_piece = [&](int piece, u32x4 (&dst)[PQ]) __attribute__((always_inline)) {
+                if (piece == 0) asm_issue6<0>(dst, voff, srd);
+                if (piece == 1) asm_issue6<384>(dst, voff, srd);
+                if (piece == 2) asm_issue6<768>(dst, voff, srd);
+                if (piece == 3) asm_issue6<1152>(dst, voff, srd);
+            };
+            // the first NB pieces go in flight BEFORE the team's MFMA window opens, the rest behind the MFMAs of the
+            // piece whose registers they reuse
+            auto head = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int s0 = 0; s0 < NB && s0 < NH; ++s0) issue_piece(s0, hv[s0]);
+            };
             auto pass = [&]() __attribute__((always_inline)) -> bool {
                 unsigned mx = 0u;
-                asm_issue6<0>(hv[0], voff, srd);
 #pragma unroll
                 for (int st = 0; st < NH; ++st) {
-                    if (st + 1 < NH) {
-                        if (st + 1 == 1) asm_issue6<384>(hv[1], voff, srd);
-                        if (st + 1 == 2) asm_issue6<768>(hv[0], voff, srd);
-                        if (st + 1 == 3) asm_issue6<1152>(hv[1], voff, srd);
-                        asm_wait6<6>(hv[st % NB]);
-                    } else {
-                        asm_wait6<0>(hv[st % NB]);
-                    }
+                    constexpr int kIssuedMax = NH;
+                    const int issued = (NB + st < kIssuedMax) ? NB + st : kIssuedMax;      // pieces issued so far
+                    const int younger = issued - 1 - st;                                    // still allowed in flight
+                    if (younger == 2) asm_wait6<12>(hv[st % NB]);
+                    else if (younger == 1) asm_wait6<6>(hv[st % NB]);
+                    else asm_wait6<0>(hv[st % NB]);
                     if (st == 0) { acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                     for (int q = 0; q < PQ; ++q)
@@ -1145,20 +1209,30 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                         for (int e = 0; e < 4; ++e)
                             acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][q][e]), b[e], acc[e & 1], 0, 0, 0);
                     }
+                    if (st + NB < NH) issue_piece(st + NB, hv[st % NB]);
                 }
                 sum = acc[0] + acc[1];
                 return __any(mx == kSentinel);
             };
+            auto probe = [&](SpinGuard& sg) __attribute__((always_inline)) {
+                // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
+                const float* pp = J.dgh + ((size_t)pos_map(p + 1, len_p, J.reverse) * B + row0 + 15) * a.ldg + (lane & 31) * 48 + 47;
+                while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+            };
             SpinGuard sg;
+            if (poll) probe(sg);
+            head();
+            ts.enter(team, 4u * (unsigned)done + (unsigned)team);
             for (;;) {
-                if (poll) {
-                    // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
-                    const float* pp = J.dgh + ((size_t)pos_map(p + 1, len_p, J.reverse) * B + row0 + 15) * a.ldg + (lane & 31) * 48 + 47;
-                    while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
-                }
                 const bool bad = pass();
                 if (!poll || !bad || sg.expired(a.err)) break;
+                probe(sg);
+                head();
             }
+            ts.leave();
+        } else {
+            ts.enter(team, 4u * (unsigned)done + (unsigned)team);      // keeps the cyclic order dense
+            ts.leave();
         }
         // every wave of the team has finished READING the previous step's partial sums, then publish this step's
         if (done > 0) { epoch += 4; team_barrier(tsync, epoch); }
@@ -1176,8 +1250,9 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             const float du = dH * (s_hp - nn) * u * (1.f - u);
             const float dr = dn * sv.w * r * (1.f - r);
             float* dgh = J.dgh + rix * a.ldg + ht * 48 + gn * 3;
-            if (fast) { dgh[0] = dr; dgh[1] = du; dgh[2] = dn * r; }
-            else { store4_sc1(dgh, dr); store4_sc1(dgh + 1, du); store4_sc1(dgh + 2, dn * r); }
+            const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r);
+            if (fast) { dgh[0] = x0; dgh[1] = x1; dgh[2] = x2; }
+            else { store4_sc1(dgh, x0); store4_sc1(dgh + 1, x1); store4_sc1(dgh + 2, x2); }
             *carryp = dH * u;
             float* dgi = J.dgi + rix * a.ldg + ht * 48 + gn * 3;
             dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
@@ -1200,19 +1275,54 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 constexpr int kGruSyncWords = 64 + 64 + 1536;   // (spare) | detection counters | XCD ids (njobs*G*HT)
 bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 512; }
 
-template <bool FWD>
-static hipError_t launch(hipStream_t st, const GruArgs& a, int grid)
+#ifdef AVAE_DIAG
+constexpr bool kDiagBuild = true;
+#else
+constexpr bool kDiagBuild = false;
+#endif
+bool gru_diag_build() { return kDiagBuild; }
+
+// Residency.  The persistent kernels exchange data between workgroups inside one launch, so every workgroup of the
+// grid must be resident at once.  A plain launch checks nothing (and the occupancy API is advisory), so the grid is
+// compared here with (workgroups per CU the occupancy query admits) x (CU count) once per kernel and launch shape,
+// and an oversize grid is refused with hipErrorCooperativeLaunchTooLarge instead of being left to the 2 s spin
+// bound.  The kernels used need one (1024-thread team kernels) or two (256-thread kernels, <= 80 SGPRs... 102 SGPRs:
+// the hardware admits >= 6 such blocks) workgroups per CU, far from the edge where the API over-reports by one.
+template <class K>
+static hipError_t resident(K kernel, int threads, int dyn_lds, int grid)
 {
-#define AVAE_GRU_CASE(KSV)                                                                                   \
-    case KSV:                                                                                                \
-        if (a.ablate & 32) {                                                                                 \
-            if (FWD) hipLaunchKernelGGL((gru_fwd_kernel<KSV, true>), dim3(grid), dim3(256), 0, st, a);       \
-            else     hipLaunchKernelGGL((gru_bwd_kernel<KSV, true>), dim3(grid), dim3(256), 0, st, a);       \
-        } else {                                                                                             \
-            if (FWD) hipLaunchKernelGGL((gru_fwd_kernel<KSV, false>), dim3(grid), dim3(256), 0, st, a);      \
-            else     hipLaunchKernelGGL((gru_bwd_kernel<KSV, false>), dim3(grid), dim3(256), 0, st, a);      \
-        }                                                                                                    \
-        break;
+    struct Entry { const void* k; int threads, lds, cap; };
+    static Entry cache[32]; static int ncache = 0;
+    const void* kp = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < ncache; ++i)
+        if (cache[i].k == kp && cache[i].threads == threads && cache[i].lds == dyn_lds)
+            return grid <= cache[i].cap ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)dyn_lds);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    const int cap = per_cu * cus;
+    if (ncache < 32) cache[ncache++] = Entry{kp, threads, dyn_lds, cap};
+    return grid <= cap ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
+}
+
+template <bool FWD, int KSV, bool DIAG>
+static hipError_t launch_ks(hipStream_t st, const GruArgs& a, int grid, bool need_resident)
+{
+    auto kernel = [] { if constexpr (FWD) return gru_fwd_kernel<KSV, DIAG>; else return gru_bwd_kernel<KSV, DIAG>; }();
+    if (need_resident) { hipError_t e = resident(kernel, 256, 0, grid); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+template <bool FWD>
+static hipError_t launch(hipStream_t st, const GruArgs& a, int grid, bool need_resident)
+{
+#ifdef AVAE_DIAG
+#define AVAE_GRU_CASE(KSV) case KSV: return a.ablate ? launch_ks<FWD, KSV, true>(st, a, grid, need_resident) : launch_ks<FWD, KSV, false>(st, a, grid, need_resident);
+#else
+#define AVAE_GRU_CASE(KSV) case KSV: return launch_ks<FWD, KSV, false>(st, a, grid, need_resident);
+#endif
     switch (a.D / 16) {
         AVAE_GRU_CASE(1)
         AVAE_GRU_CASE(4)
@@ -1221,15 +1331,14 @@ static hipError_t launch(hipStream_t st, const GruArgs& a, int grid)
         default: return hipErrorInvalidValue;
     }
 #undef AVAE_GRU_CASE
-    return hipGetLastError();
 }
 
 static hipError_t check(const GruArgs& a, int* grid)
 {
     if (!gru_dim_supported(a.D) || a.njobs < 1 || a.njobs > kMaxGruJobs) return hipErrorInvalidValue;
     if (a.rows_per_group % 16 || a.G * a.rows_per_group < a.B) return hipErrorInvalidValue;
+    if (!kDiagBuild && a.ablate) return hipErrorInvalidValue;
     *grid = a.njobs * a.G * (a.D / 16);
-    if (*grid > 512) return hipErrorInvalidValue;     // residency: 2 workgroups per CU x 256 CUs
     return hipSuccess;
 }
 
@@ -1268,33 +1377,51 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd)
     return e;
 }
 
+template <class K>
+static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int lds_bytes)
+{
+    static const void* attr_done[8]; static int nattr = 0;
+    const void* kp = reinterpret_cast<const void*>(kernel);
+    bool seen = false;
+    for (int i = 0; i < nattr; ++i) seen |= attr_done[i] == kp;
+    if (!seen) {
+        hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        if (nattr < 8) attr_done[nattr++] = kp;
+    }
+    const int grid = a.njobs * (a.B / 64) * 32;
+    hipError_t e = resident(kernel, 1024, lds_bytes, grid);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
         e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
         // D = 512, two directions, B = 64 x (1..4): four independent 16-row teams per CU, weights in LDS
-        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !(a.ablate & ~(16 | 128 | 256)) && a.item_pipeline == 2) {
-            const int lds_bytes = (4 * 3 * 8 * 256 + kTeams * 4 * 3 * 256 + kTeams * 256) * 4 + 64;
-            static bool attr_set = false;
-            if (!attr_set) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-                if (e != hipSuccess) return e;
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(gru_fwd_team_kernel, dim3(a.njobs * (a.B / 64) * 32), dim3(1024), lds_bytes, st, a);
-            return hipGetLastError();
+        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && a.item_pipeline == 2) {
+            const int lds_bytes = (4 * 3 * 8 * 256 + kTeams * 4 * 3 * 256 + kTeams * 256) * 4 + 128;
+#ifdef AVAE_DIAG
+            if (a.ablate) {
+                if (!(a.ablate & ~(16 | 128 | 256))) return launch_team(st, gru_fwd_team_kernel<true>, a, lds_bytes);
+            } else
+#endif
+            return launch_team(st, gru_fwd_team_kernel<false>, a, lds_bytes);
         }
         // benchmark geometry (D = 512, two full 16-row chunks per workgroup): software-pipelined kernel
         if (a.D == 512 && a.rows_per_group == 32 && a.B % 32 == 0 && a.G * 32 == a.B && !a.ablate && a.item_pipeline) {
+            e = resident(gru_fwd_item_kernel, 256, 0, grid); if (e != hipSuccess) return e;
             hipLaunchKernelGGL(gru_fwd_item_kernel, dim3(grid), dim3(256), 0, st, a);
             return hipGetLastError();
         }
-        return launch<true>(st, a, grid);
+        return launch<true>(st, a, grid, true);
     }
     for (int p = a.p_begin; p < a.p_end; ++p) {
         GruArgs b = a; b.p_begin = p; b.p_end = p + 1;
-        e = launch<true>(st, b, grid); if (e != hipSuccess) return e;
+        e = launch<true>(st, b, grid, false); if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -1308,27 +1435,20 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
         if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !a.ablate && a.item_pipeline == 2 &&
             a.p_begin == 0 && a.p_end == a.S && !a.job[0].dh0 && !a.job[1].dh0) {
             const int lds_bytes = (4 * 24 * 256 + kTeams * 4 * 256 + 64) * 4 + 64;
-            static bool attr_set = false;
-            if (!attr_set) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-                if (e != hipSuccess) return e;
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(gru_bwd_team_kernel, dim3(a.njobs * (a.B / 64) * 32), dim3(1024), lds_bytes, st, a);
-            return hipGetLastError();
+            return launch_team(st, gru_bwd_team_kernel<2>, a, lds_bytes);
         }
-        return launch<false>(st, a, grid);
+        return launch<false>(st, a, grid, true);
     }
     // one launch per step (descending); the dh0 tail (p = -1) is its own launch
     for (int p = a.p_end - 1; p >= a.p_begin; --p) {
         GruArgs b = a; b.p_begin = p; b.p_end = p + 1;
         for (int i = 0; i < b.njobs; ++i) b.job[i].dh0 = nullptr;
-        e = launch<false>(st, b, grid); if (e != hipSuccess) return e;
+        e = launch<false>(st, b, grid, false); if (e != hipSuccess) return e;
         if (p == 0) {
             bool any = false; for (int i = 0; i < a.njobs; ++i) any |= a.job[i].dh0 != nullptr;
             if (any) {
                 GruArgs d = a; d.p_begin = 0; d.p_end = 0;   // loop runs p = -1 only
-                e = launch<false>(st, d, grid); if (e != hipSuccess) return e;
+                e = launch<false>(st, d, grid, false); if (e != hipSuccess) return e;
             }
         }
     }

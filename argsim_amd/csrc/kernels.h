@@ -75,11 +75,13 @@ struct GruArgs {
     int item_pipeline;    // 1: use the software-pipelined D = 512 forward kernel where its geometry applies
     int stagger;          // 1: delay the second half of the grid by ~half a step (co-resident chains de-phased)
     int force_slow;       // 1: never use the same-XCD L2 fast path
+    int turn;             // D = 512 team kernels: 0 = waves arbitrate freely, 1 = MFMA windows in cyclic team order, 2 = FIFO tickets
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
 bool gru_dim_supported(int D);
+bool gru_diag_build();     // true: built with -DAVAE_DIAG (ablation / stamp instantiations present)
 
 // ---------------------------------------------------------------- small kernels (ops.hip)
 struct PrepArgs {
@@ -135,7 +137,8 @@ hipError_t argmax_rows(hipStream_t st, const float* logits, int32_t* pred, int n
 hipError_t colsum(hipStream_t st, const float* X, int M, int N, int ldx, float* out, const int32_t* m_dev);
 hipError_t add3(hipStream_t st, float* out, const float* a, const float* b, const float* c, int64_t n);
 
-struct AdamArgs { float* p; const float* g; float* m; float* v; int64_t n; float lr_t, b1, b2, eps; };
+struct AdamArgs { float* p; const float* g; float* m; float* v; int64_t n; float lr_t, b1, b2, eps;
+                  const int* skip_if; };   // device word: non-zero -> the update is a no-op (GRU time-out flag)
 hipError_t adam_tf(hipStream_t st, const AdamArgs& a);
 
 // natural <-> G16 row permutation of a (3D, cols) matrix (cols = 1 for biases)

@@ -45,8 +45,9 @@ struct avae_ctx {
     float *P = nullptr, *G = nullptr, *M = nullptr, *Vv = nullptr;
     int64_t step = 0;
     avae_grad_hook hook = nullptr; void* hook_user = nullptr;
+    std::vector<int> hook_pending;     // buckets complete but not yet announced (see hook_flush)
     int persistent = 1;
-    int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2, gru_turn = 0;
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
     std::vector<GruP> enc;     // per layer: W = [fwd;bwd] (6D,In), R = [fwd;bwd], bW (6D), bR (6D)
@@ -79,6 +80,15 @@ namespace {
 #define AV_TRY(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
 
 int fail(avae_ctx* h, const std::string& m) { h->err = m; return 1; }
+
+// persistent GRU launches: the residency check of gru.hip answers hipErrorCooperativeLaunchTooLarge
+#define AV_GRU(expr)                                                                                                \
+    do { hipError_t e_ = (expr);                                                                                    \
+         if (e_ == hipErrorCooperativeLaunchTooLarge)                                                               \
+             return fail(h, "persistent GRU kernel: its workgroups cannot all be resident on this device at once (occupancy query x CU count < grid); " \
+                            "run with avae_set_option(\"persistent\", 0)");                                         \
+         if (e_ != hipSuccess) { char b_[512]; snprintf(b_, sizeof b_, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+             h->err = b_; return 1; } } while (0)
 
 // kernel classes for the timing hook: 0 = MFMA GEMM, 1 = GRU forward, 2 = GRU backward
 struct Timed {
@@ -324,7 +334,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.turn = h->gru_turn; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.gi = w.e_gi[i] + d * 3 * D;
@@ -337,7 +347,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             j.reverse = d;
         }
         { Timed t(h, 1, 2.0 * 2 * Ss * (double)B * D * 3 * D);
-          AV_CHECK(gru_forward(h->stream, a, h->persistent != 0)); }
+          AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.e_hs[i]; In = 2 * D;
     }
     AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D));
@@ -365,7 +375,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.turn = h->gru_turn; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.gi = w.d_gi[i]; j.R = h->P + p.R; j.bR = h->P + p.bR;
         j.h0 = state_in + state_stride * i;
@@ -374,7 +384,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         j.hp = save ? w.d_hp[i] : nullptr;
         j.reverse = 0;
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
-          AV_CHECK(gru_forward(h->stream, a, h->persistent != 0)); }
+          AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.d_hd[i];
     }
     return 0;
@@ -410,10 +420,24 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     return 0;
 }
 
+// Data-parallel hook protocol (include/argsim_vae.h).  A bucket whose gradients are final is not announced at once
+// but right AFTER the next persistent GRU launch has been enqueued (or at the end of backward): a collective the
+// callee starts then is ordered behind that launch and overlaps the GEMM phase that follows it.  Just BEFORE every
+// persistent GRU launch the hook is called with bucket = AVAE_HOOK_FENCE so that the callee makes the compute stream
+// wait for the collectives in flight: a persistent launch needs every CU (its workgroups exchange data inside the
+// launch) and must never share the device with a kernel that may wait on a peer GPU.
 void fire_hook(avae_ctx* h, int bucket)
 {
-    if (h->hook && bucket >= 0 && bucket < (int)h->buckets.size())
-        h->hook(h->hook_user, bucket, h->buckets[bucket].first, h->buckets[bucket].second);
+    if (h->hook && bucket >= 0 && bucket < (int)h->buckets.size()) h->hook_pending.push_back(bucket);
+}
+void hook_fence(avae_ctx* h)
+{
+    if (h->hook) h->hook(h->hook_user, AVAE_HOOK_FENCE, 0, 0);
+}
+void hook_flush(avae_ctx* h)
+{
+    for (int b : h->hook_pending) h->hook(h->hook_user, b, h->buckets[b].first, h->buckets[b].second);
+    h->hook_pending.clear();
 }
 
 int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
@@ -424,6 +448,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     Sched sc = schedule(h);
     hipStream_t st = h->stream;
     float* G = h->G; const float* P = h->P;
+    h->hook_pending.clear();
     AV_CHECK(hipMemsetAsync(G, 0, sizeof(float) * h->numel, st));
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
@@ -445,14 +470,16 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.turn = h->gru_turn; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
         j.dh0 = w.dh0 + (size_t)i * B * D; j.carry = w.carry;
         j.dbW = G + p.bW; j.dbR = G + p.bR;
+        hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
-          AV_CHECK(gru_backward(st, a, h->persistent != 0)); }
+          AV_GRU(gru_backward(st, a, h->persistent != 0)); }
+        hook_flush(h);
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt));
         AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
@@ -487,7 +514,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.turn = h->gru_turn; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
@@ -495,8 +522,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             j.dh0 = nullptr; j.carry = w.carry + (size_t)d * B * D;
             j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
+        hook_fence(h);
         { Timed t(h, 2, 2.0 * 2 * (Ss - 1) * (double)B * D * 3 * D);
-          AV_CHECK(gru_backward(st, a, h->persistent != 0)); }
+          AV_GRU(gru_backward(st, a, h->persistent != 0)); }
+        hook_flush(h);
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         for (int d = 0; d < 2; ++d)
@@ -510,6 +539,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_CHECK(embed_scatter_add(st, G + h->oE, w.src_tm, w.demb_src, rs, D, V));
     AV_CHECK(embed_scatter_add(st, G + h->oE, w.lead, w.demb_tgt, rt, D, V));
     fire_hook(h, 2 + 2 * L);
+    hook_flush(h);
     return 0;
 }
 
@@ -610,9 +640,9 @@ int avae_create(const avae_config* cfg, int device, avae_handle* out)
 {
     if (!cfg || !out) { g_create_err = "null argument"; return 1; }
     *out = nullptr;
-    if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 64, 256, 512"; return 1; }
+    if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 64, 256, 512 (the GRU kernels are instantiated for these widths only; the reference leaves dim_emb free, config.json uses 512)"; return 1; }
     if (cfg->compute_dtype < 0 || cfg->compute_dtype > 2) { g_create_err = "compute_dtype must be 0 (fp32 MFMA), 1 (bf16 GEMM operands) or 2 (fp32 via split bf16 MFMA)"; return 1; }
-    if (cfg->dim_rep % 4 || cfg->dim_tgt % 4 || cfg->rnn_layers < 1 || cfg->rnn_layers > 8) { g_create_err = "dim_rep and dim_tgt must be multiples of 4; 1 <= rnn_layers <= 8"; return 1; }
+    if (cfg->dim_rep % 4 || cfg->dim_tgt % 4 || cfg->rnn_layers < 1 || cfg->rnn_layers > 8) { g_create_err = "dim_rep and dim_tgt must be multiples of 4 (16-byte rows); 1 <= rnn_layers <= 8"; return 1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available: the gfx950 kernels cannot run (no CPU fallback)"; return 1; }
     if (device < 0 || device >= ndev) { g_create_err = "bad device index"; return 1; }
@@ -723,7 +753,12 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_item")) { h->gru_item = value; return 0; }
     if (!strcmp(key, "gru_stagger")) { h->gru_stagger = value; return 0; }
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
-    if (!strcmp(key, "gru_ablate")) { h->gru_ablate = value; return 0; }
+    if (!strcmp(key, "gru_ablate")) {
+        // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
+        if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");
+        h->gru_ablate = value; return 0;
+    }
+    if (!strcmp(key, "gru_turn")) { h->gru_turn = value; return 0; }
     if (!strcmp(key, "timing")) { h->timing = value; h->timing_on = value; h->stamps_used = 0; return 0; }
     if (!strcmp(key, "timing_pause")) { h->timing = value ? 0 : h->timing_on; return 0; }
     return fail(h, "unknown option");
@@ -804,7 +839,7 @@ int avae_adam_step(avae_handle h)
     Sched sc = schedule(h);
     const double b1 = 0.9, b2 = 0.999;
     double t = (double)h->step + 1.0;
-    AdamArgs a{h->P, h->G, h->M, h->Vv, h->numel, (float)(sc.lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t))), 0.9f, 0.999f, 1e-8f};
+    AdamArgs a{h->P, h->G, h->M, h->Vv, h->numel, (float)(sc.lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t))), 0.9f, 0.999f, 1e-8f, h->errw};
     AV_CHECK(adam_tf(h->stream, a));
     h->step += 1;
     return 0;
@@ -865,7 +900,7 @@ int avae_encode(avae_handle h, const int32_t* src, int32_t b, int32_t t, float* 
     const size_t n = (size_t)b * h->cfg.dim_rep * sizeof(float);
     if (z_out) AV_CHECK(hipMemcpyAsync(z_out, w.mu, n, hipMemcpyDeviceToDevice, h->stream));
     if (lv_out) AV_CHECK(hipMemcpyAsync(lv_out, w.lv, n, hipMemcpyDeviceToDevice, h->stream));
-    return 0;
+    return check_gru_err(h);       // synchronises: a z computed past a timed-out wait must not be handed out silently
 }
 
 int avae_decode_init(avae_handle h, const float* z, int32_t b, float* state_out)
@@ -900,7 +935,8 @@ int avae_decode_step(avae_handle h, const int32_t* lead, const float* state_in, 
     AV_CHECK(hipSetDevice(h->device));
     Ws w;
     AV_TRY(get_ws(h, w, b, 1, 1, false));
-    return decode_step_ws(h, w, lead, state_in, b, pred_out, state_out);
+    AV_TRY(decode_step_ws(h, w, lead, state_in, b, pred_out, state_out));
+    return check_gru_err(h);
 }
 
 int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, int32_t* out_ids, int32_t* n_steps)

@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a)
     float4* m = reinterpret_cast<float4*>(a.m);
     float4* v = reinterpret_cast<float4*>(a.v);
     const float c1 = 1.f - a.b1, c2 = 1.f - a.b2;
+    // a persistent GRU launch of this step gave up on a wait: its gradients are garbage, the update is skipped
+    // (uniform branch; the host raises at its next synchronising call)
+    if (a.skip_if && *a.skip_if != 0) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 P = p[i], G = g[i], Mv = m[i], V = v[i];
 #define AVAE_ADAM1(f) Mv.f = a.b1 * Mv.f + c1 * G.f; V.f = a.b2 * V.f + c2 * G.f * G.f; P.f -= a.lr_t * Mv.f / (sqrtf(V.f) + a.eps);

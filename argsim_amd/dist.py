@@ -4,8 +4,11 @@ The reference is single-GPU (src/train.py:14,26); this is the extension BASELINE
 (SURVEY.md section 8e).  Sentences are independent inside a step and parameters are replicated,
 so rank r takes rows [r*B/P, (r+1)*B/P) of the global batch.  There is ONE data-path collective:
 the gradient all-reduce, issued per bucket of the flat gradient buffer in backward-completion
-order from a hook that fires while backward is still being enqueued, on a side HIP stream, so the
-reduction of the decoder's gradients overlaps the encoder's backward.
+order from a hook that fires while backward is still being enqueued, on a side HIP stream.  The
+library announces a finished bucket right after it has enqueued the NEXT persistent GRU launch and
+asks for a fence (bucket -1) before every such launch: the collectives therefore run beside the
+GEMM phases of backward and never beside a persistent launch, which needs every CU resident
+(include/argsim_vae.h, avae_grad_hook).  RCCL with world > 1 has not run on hardware yet.
 
 Exactness: loss_gen is a mean over the GLOBAL token count N (model.py:181) and loss_kld a mean
 over the global (B, R) (model.py:184), so every rank scales its local gradients by 1/N_global and
@@ -39,12 +42,30 @@ class GradReducer:
         else:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def fence(self):
+        """the compute stream waits for every collective in flight (called before a persistent GRU launch)"""
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
+        else:
+            for w in self.pending:
+                w.wait()
+            self.pending = []
+
     def wait(self):
         for w in self.pending:
             w.wait()
         self.pending = []
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
+
+
+def rank_seed(seed, rank):
+    """a 64-bit RNG key per rank from one shared key (splitmix64 finaliser over seed + golden-ratio * (rank + 1))"""
+    m = (1 << 64) - 1
+    x = (seed + 0x9E3779B97F4A7C15 * (rank + 1)) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
 
 
 def shard_rows(B, rank, world):
@@ -75,13 +96,17 @@ class DataParallel:
         self.reducer = GradReducer(model.grads, model.buckets(), group, self.comm_stream)
         self.overlap = overlap
         if overlap:
-            model.set_grad_hook(lambda b, off, cnt: self.reducer.reduce_bucket(b))
+            model.set_grad_hook(lambda b, off, cnt: self.reducer.fence() if b < 0 else self.reducer.reduce_bucket(b))
 
     def broadcast_params(self, flat_params):
         dist.broadcast(flat_params, src=0, group=self.group)
 
     def train_step(self, src_local, tgt_local, n_tok_global, b_global, seed=None, keep_mask=None, eps=None):
-        """one ELBO step on this rank's shard.  n_tok_global: tokens of the global batch."""
+        """one ELBO step on this rank's shard.  n_tok_global: tokens of the global batch.
+        seed=None: the model's own (seed, step, call) key, decorrelated per rank -- the reference draws word dropout
+        and eps i.i.d. over the whole batch (model.py:93,153), so two shards must not share one stream."""
+        if seed is None and hasattr(self.m, 'next_seed'):
+            seed = rank_seed(self.m.next_seed(), self.rank)
         self.m.forward_backward(src_local, tgt_local, seed=seed, keep_mask=keep_mask, eps=eps,
                                 n_tok_global=n_tok_global, b_global=b_global)
         if not self.overlap:

@@ -95,8 +95,8 @@ class VAE:
 
     def _ids(self, x):
         """-> contiguous int32 cuda tensor (B, S)"""
-        if isinstance(x, torch.Tensor):
-            return x.to(device=self.device, dtype=torch.int32).contiguous()
+        if isinstance(x, torch.Tensor):       # a pinned host tensor (train.pinned) crosses asynchronously
+            return x.to(device=self.device, dtype=torch.int32, non_blocking=True).contiguous()
         return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32)).to(self.device, non_blocking=True)
 
     def trim(self, x):
@@ -104,7 +104,10 @@ class VAE:
         drops the all-eos tail columns.  Device tensors are passed through (padding columns are
         masked inside the kernels and cost only time)."""
         if isinstance(x, torch.Tensor):
-            return x
+            if x.is_cuda:
+                return x
+            m = int((x != self.eos).sum(1).max()) if x.numel() else 0
+            return x[:, :max(m, 1)]
         x = np.asarray(x)
         m = int((x != self.eos).sum(1).max()) if x.size else 0
         return x[:, :max(m, 1)]
@@ -198,9 +201,13 @@ class VAE:
         self._ck(self._l.avae_set_grad_hook(self._h, self._hook_ref, None))
 
     # ------------------------------------------------------------------ training
+    def next_seed(self):
+        """the RNG key the next step would use when none is passed: a function of (seed, step, call count)"""
+        return (self._seed * 0x9E3779B1 + self.step * 1000003 + self._calls) & 0xFFFFFFFFFFFFFFFF
+
     def _rng_args(self, seed, keep_mask, eps):
         if seed is None:
-            seed = (self._seed * 0x9E3779B1 + self.step * 1000003 + self._calls) & 0xFFFFFFFFFFFFFFFF
+            seed = self.next_seed()
         self._calls += 1
         km = ep = None
         if keep_mask is not None:

@@ -6,9 +6,10 @@ validate over the whole validation array in chunks of ``batch_valid`` -> every 4
 steps save a checkpoint named ``<trial><step // 10000>`` (src/train.py:115-121).
 
 Differences: scalars go to ``<log>/<trial>.jsonl`` (names step_errt / step_loss_gen / step_loss_kld
-as in src/train.py:98-102) instead of TensorBoard; ``--profile`` times warm forward passes on
-valid[:32] (src/train.py:76-82) and tells you the rocprofv3 command for a kernel trace; with
-torchrun (WORLD_SIZE > 1) the batch is sharded over data-parallel replicas (argsim_amd/dist.py).
+as in src/train.py:98-102) instead of TensorBoard; ``--profile`` traces one warm run of the validation
+loss on valid[:32] (src/train.py:76-82) in a child process under rocprofv3 and leaves the per-kernel
+summary in ``<log>/<trial>_profile/``; with torchrun (WORLD_SIZE > 1) the batch is sharded over
+data-parallel replicas (argsim_amd/dist.py), every rank tokenising only its own rows.
 """
 import argparse
 import json
@@ -36,29 +37,49 @@ def parse_args(argv=None):
     p.add_argument('--valid-every', default=250, type=int)
     p.add_argument('--kl-beta', default=1.0, type=float, help="multiplies the tanh KL anneal (1 = reference)")
     p.add_argument('--free-bits', default=0.0, type=float, help="per-dimension KL floor (0 = reference)")
+    p.add_argument('--save-tf', action='store_true', help="also write every checkpoint as TF V2 checkpoint files "
+                   "(<ckpt>/<trial><round>.index/.data-*), the format the reference's eval scripts restore; CudnnGRU "
+                   "names are unverified against a real TensorFlow (ckpt.py)")
+    p.add_argument('--profile-run', action='store_true', help=argparse.SUPPRESS)    # the child that --profile traces
     return p.parse_args(argv)
 
 
-def batch(size, path, vocab, seed, kudo, max_len):
-    """endless (src, tgt) stream of eos-packed int32 batches (src/train.py:54-68)."""
+def batch(size, path, vocab, seed, kudo, max_len, rank=0, world=1):
+    """endless stream of (src, tgt) int32 arrays, rows padded with eos to the longest row (src/train.py:54-68):
+    the corpus lines are visited in the order of util_np.sample and cut into consecutive groups of ``size``.
+    Data parallel: every rank walks the same index stream but tokenises only its own rows
+    [rank * size / world, (rank + 1) * size / world) of each group."""
+    import itertools
     import numpy as np
+    from .dist import shard_rows
     from .util_io import load_txt
     from .util_np import sample, vpack
     from .util_sp import encode_capped, encode_capped_sample_pair
-    eos = vocab.eos_id()
-    pac = lambda arrs: vpack(arrs, (size, max(map(len, arrs))), eos, np.int32)  # noqa: E731
-    enc = encode_capped_sample_pair if kudo else encode_capped
-    raw = tuple(load_txt(path))
-    bat = []
-    for i in sample(len(raw), seed):
-        if size == len(bat):
-            if kudo:
-                src, tgt = map(pac, zip(*bat))
-            else:
-                src = tgt = pac(bat)
-            yield src, tgt
-            bat = []
-        bat.append(enc(vocab, raw[i], cap=max_len))
+    lines = tuple(load_txt(path))
+    lo, hi = shard_rows(size, rank, world)
+    pad = vocab.eos_id()
+
+    def pack(rows):
+        return vpack(rows, (len(rows), max(len(r) for r in rows)), pad, np.int32)
+
+    picks = sample(len(lines), seed)
+    while True:
+        mine = list(itertools.islice(picks, size))[lo:hi]
+        if kudo:      # two independent sampled segmentations of every line (--sample)
+            pairs = [encode_capped_sample_pair(vocab, lines[i], cap=max_len) for i in mine]
+            yield pack([a for a, _ in pairs]), pack([b for _, b in pairs])
+        else:
+            ids = pack([encode_capped(vocab, lines[i], cap=max_len) for i in mine])
+            yield ids, ids
+
+
+def pinned(gen):
+    """host batches -> page-locked torch tensors, so the H2D copy of VAE._ids is asynchronous (the counterpart of the
+    tf.data iterator handing device-ready tensors to the graph, util_tf.py:16-23)"""
+    import torch
+    for src, tgt in gen:
+        a = torch.from_numpy(src).pin_memory()
+        yield a, (a if tgt is src else torch.from_numpy(tgt).pin_memory())
 
 
 def pipe(gen, prefetch=1):
@@ -91,10 +112,46 @@ def summ(model, valid, batch_valid):
     return float(errt.mean()), float(lgen.mean()), float(lkld.mean())
 
 
+def profile(A, argv):
+    """--profile (src/train.py:76-82): the reference writes ONE fully traced run of the validation loss on
+    valid[:32] to TensorBoard.  Here the same run happens in a child process under ``rocprofv3 --kernel-trace
+    --stats`` (started before this process touches the GPU); the per-kernel summary lands in
+    <log>/<trial>_profile/ and its top rows are printed.  Without rocprofv3 on PATH the child runs bare and only
+    its HIP-event class timings are printed."""
+    import glob
+    import shutil
+    import subprocess
+    from .util_io import load_json, pform
+    out = pform(load_json(A.config)['paths']['log'], A.trial, '_profile')
+    os.makedirs(out, exist_ok=True)
+    child = [sys.executable, '-m', 'argsim_amd.train', '--profile-run', '--trial', A.trial, '--config', A.config,
+             '--gpu', str(A.gpu), '--seed', str(A.seed)] + (['--ckpt', A.ckpt] if A.ckpt else [])
+    tool = shutil.which('rocprofv3')
+    cmd = ([tool, '--kernel-trace', '--stats', '-d', out, '--'] if tool else []) + child
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    text = res.stdout.decode(errors='replace')
+    print('\n'.join(l for l in text.splitlines() if l.startswith('{')))
+    if res.returncode:
+        sys.exit("profile run failed:\n" + text[-2000:])
+    for path in sorted(glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True))[-1:]:
+        print("kernel summary:", path)
+        with open(path) as f:
+            for i, line in enumerate(f):
+                if i > 12:
+                    break
+                print("   ", line.rstrip()[:160])
+
+
 def main(argv=None):
     A = parse_args(argv)
-    if not A.rounds and not A.profile:
+    if not A.rounds and not A.profile and not A.profile_run:
         sys.exit("nothing to do")
+    if A.profile and not A.profile_run:
+        profile(A, argv)
+        if not A.rounds:
+            sys.exit("profiling done")
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', A.gpu if world == 1 else '0'))
@@ -103,32 +160,38 @@ def main(argv=None):
     import torch
     from . import ckpt
     from .model import VAE
-    from .util import Record
+    from types import SimpleNamespace
     from .util_io import load_json, pform
     from .util_sp import load_spm
 
     config = load_json(A.config)
-    P, Cm, T = Record(config['paths']), Record(config['model']), Record(config['train'])
+    P, T, Cm = SimpleNamespace(**config['paths']), SimpleNamespace(**config['train']), dict(config['model'])
     vocab = load_spm(P.vocab)
     valid = np.load(P.valid)
     torch.cuda.set_device(local)
     model = VAE('train', device=local, seed=A.seed, kl_beta=A.kl_beta, free_bits=A.free_bits, **Cm)
 
-    if A.profile:
+    if A.profile_run:
+        # the traced child of --profile (src/train.py:76-82 via util_tf.profile, src/util_tf.py:9-13): three warm-up
+        # runs, then ONE run of the validation loss on valid[:32] with per-class HIP-event stamps
         x = valid[:32]
         for _ in range(3):
             model.eval(x, x)
+        model.set_option('timing', 1)
         t0 = time.perf_counter()
         model.eval(x, x)
-        print("valid[:32] forward: %.3f ms;  kernel trace: rocprofv3 --kernel-trace --stats -- python -m argsim_amd.train --profile ..."
-              % (1e3 * (time.perf_counter() - t0)))
+        wall = 1e3 * (time.perf_counter() - t0)
+        tm = model.timing_collect()
+        print(json.dumps(dict(valid32_forward_ms=wall, classes={k: dict(ms=v[0], launches=v[1], tflops=(v[2] / (v[0] * 1e-3) / 1e12 if v[0] else 0.0))
+                                                                  for k, v in tm.items()})))
+        return
     if not A.rounds:
         sys.exit("profiling done")
 
     dp = None
     if world > 1:
         import torch.distributed as dist
-        from .dist import DataParallel
+        from .dist import DataParallel, global_token_count
         dist.init_process_group('nccl')
         dp = DataParallel(model)
     if A.ckpt:
@@ -136,9 +199,7 @@ def main(argv=None):
     if dp:
         dp.broadcast_params(model.state)
 
-    assert T.batch_train % world == 0
-    per = T.batch_train // world
-    stream = pipe(batch(T.batch_train, P.train, vocab, A.seed, A.sample, T.max_len), A.prefetch)
+    stream = pipe(pinned(batch(T.batch_train, P.train, vocab, A.seed, A.sample, T.max_len, rank, world)), A.prefetch)
     os.makedirs(P.log, exist_ok=True)
     os.makedirs(P.ckpt, exist_ok=True)
     log = open(pform(P.log, A.trial, '.jsonl'), 'a') if rank == 0 else None
@@ -148,10 +209,9 @@ def main(argv=None):
             t0 = time.perf_counter()
             for _ in range(A.valid_every):
                 src, tgt = next(stream)
-                if dp:
-                    n_glob = float((tgt != eos).sum() + len(tgt))
-                    sl = slice(rank * per, (rank + 1) * per)
-                    dp.train_step(src[sl], tgt[sl], n_glob, float(len(tgt)))
+                if dp:      # this rank's shard; the ELBO means are over the GLOBAL token / row counts (model.py:181,184)
+                    n_glob = global_token_count(int((tgt != eos).sum()) + len(tgt), device=model.device)
+                    dp.train_step(src, tgt, n_glob, float(T.batch_train))
                 else:
                     model.train_step(src, tgt)
             lg, lk, lo = model.losses()
@@ -166,6 +226,8 @@ def main(argv=None):
                 print(rec)
         if rank == 0:
             ckpt.save(model, pform(P.ckpt, A.trial, model.step // 10000))
+            if A.save_tf:
+                ckpt.save_tf(model, pform(P.ckpt, A.trial, model.step // 10000))
 
 
 if __name__ == '__main__':

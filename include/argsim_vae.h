@@ -100,10 +100,15 @@ int  avae_train_step(avae_handle h, const int32_t* src, const int32_t* tgt,
                      const uint8_t* keep_mask, const float* eps);
 /* loss_gen, loss_kld, loss of the last forward (synchronises the stream) */
 int  avae_get_losses(avae_handle h, float out[3]);
-/* data-parallel hook: called on the host while backward is being ENQUEUED, once per bucket of
- * the flat gradient buffer that no later kernel of this step writes again.  The callee
- * typically records an event on the compute stream and issues the RCCL all-reduce of
- * grads[offset, offset+count) on a side stream.                                         */
+/* data-parallel hook, called on the host while backward is being ENQUEUED.
+ *   bucket >= 0: grads[offset, offset+count) is final (no later kernel of this step writes it).  The call is made
+ *                right after the next persistent GRU launch has been enqueued (or at the end of backward), so a
+ *                collective the callee orders behind the compute stream's current tail (event + side stream) runs
+ *                beside the GEMM phase that follows that launch.
+ *   bucket == AVAE_HOOK_FENCE (offset = count = 0): a persistent GRU launch comes next; the callee must make the
+ *                compute stream wait for every collective it has in flight (the launch needs all CUs resident and
+ *                must not share the device with a kernel that may wait on a peer GPU).                          */
+enum { AVAE_HOOK_FENCE = -1 };
 typedef void (*avae_grad_hook)(void* user, int bucket, int64_t offset, int64_t count);
 int  avae_set_grad_hook(avae_handle h, avae_grad_hook hook, void* user);
 

@@ -6,8 +6,10 @@ from argsim_amd.model import VAE
 m = VAE('train', seed=0, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 m.step = 20000
 ids = torch.as_tensor(synth.batch(256, 64, 8192, seed=0)).cuda()
-names = ['Aload+poll', 'mfma', 'barriers+write', 'gates+store', '-', 'loop']
-for ab in (128, 128 | 256):
+names = ['Aload+poll', 'mfma', 'barriers+write', 'gates+store', 'turn-wait', 'loop']
+for turn in (0, 1, 2):
+  m.set_option('gru_turn', turn)
+  for ab in (128, 128 | 256, 128 | 16):
     for i in range(2): m.encode(ids)
     m.set_option('gru_ablate', ab)
     out = (C.c_uint64 * 32)()
@@ -17,4 +19,4 @@ for ab in (128, 128 | 256):
     m.set_option('gru_ablate', 0)
     n, steps = out[10], out[8] / max(out[10], 1)
     per = [out[i] / max(n, 1) / max(steps, 1) * 0.01 for i in range(6)]
-    print('ablate', ab, 'team-launches', n, 'steps %.1f' % steps, ' '.join('%s %.2f' % (a, b) for a, b in zip(names, per)), 'total %.2f us/step' % sum(per), flush=True)
+    print('turn', turn, 'ablate', ab, 'team-launches', n, 'steps %.1f' % steps, ' '.join('%s %.2f' % (a, b) for a, b in zip(names, per)), 'total %.2f us/step' % sum(per), flush=True)

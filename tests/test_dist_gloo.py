@@ -60,6 +60,7 @@ class OracleModel:
         self.grads.copy_(g)
         if self.hook:
             for i, (off, cnt) in enumerate(self.buckets()):
+                self.hook(-1, 0, 0)            # AVAE_HOOK_FENCE: what the library sends before a persistent launch
                 self.hook(i, off, cnt)
 
     def adam_step(self):

@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 
 from argsim_amd import util_np, util_sp
-from argsim_amd.util import Record, comp
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
@@ -43,12 +42,6 @@ def test_sample_does_not_touch_global_rng():
     np.random.seed(123)
     list(islice(util_np.sample(9, 4), 30))
     assert np.random.rand() == a
-
-
-def test_record_and_comp():
-    r = Record({'a': 1}, b=2)
-    assert r.a == 1 and r['b'] == 2 and dict(**r) == {'a': 1, 'b': 2} and len(r) == 2
-    assert comp(lambda x: x + 1, lambda x: 2 * x, lambda x: x - 3)(5) == 5
 
 
 def test_sentence_splitter():
@@ -118,8 +111,25 @@ def test_batch_generator_and_pipe(vocab):
     gen2 = batch(4, path, v, seed=0, kudo=True, max_len=16)
     s2, t2 = next(gen2)
     assert s2.shape[0] == t2.shape[0] == 4
+    # data parallel: the ranks' shards are the row blocks of the single-process batch, batch after batch
+    whole = batch(8, path, v, seed=0, kudo=False, max_len=16)
+    shards = [batch(8, path, v, seed=0, kudo=False, max_len=16, rank=r, world=2) for r in range(2)]
+    for _ in range(3):
+        full = next(whole)[0]
+        for r, g in enumerate(shards):
+            part = next(g)[0]
+            rows = full[4 * r:4 * r + 4]
+            assert part.shape[0] == 4 and part.shape[1] <= rows.shape[1]
+            assert (rows[:, :part.shape[1]] == part).all() and (rows[:, part.shape[1]:] == v.eos_id()).all()
     got = list(islice(pipe(iter(range(10)), prefetch=3), 10))
     assert got == list(range(10))
+
+
+def test_rank_seeds_are_distinct_and_stable():
+    from argsim_amd.dist import rank_seed
+    keys = [rank_seed(12345, r) for r in range(8)]
+    assert len(set(keys)) == 8 and all(0 <= k < 2 ** 64 for k in keys)
+    assert keys == [rank_seed(12345, r) for r in range(8)] and rank_seed(12346, 0) != keys[0]
 
 
 def test_checkpoint_tf_name_roundtrip():
@@ -211,3 +221,33 @@ def test_data_prep_ibm_and_iac(tmp_path):
     lines = open(out2 / 'train.txt').read().splitlines()
     assert len(lines) == 30                                                 # the empty post was dropped
     assert all(len(v2.encode_as_ids(l)) <= 16 for l in lines) and all(l == l.lower() for l in lines)
+
+
+def test_checkpoint_audit_is_loud():
+    """restore refuses, with names, what does not fit the model: wrong shapes always, missing / unknown keys when strict"""
+    from argsim_amd import ckpt
+
+    class Stub:
+        names = ['a/kernel', 'a/bias']
+        shapes = {'a/kernel': (2, 3), 'a/bias': (3,)}
+        step = 0
+
+        def __init__(self):
+            self.got = {}
+
+        def set_tensor(self, k, v, kind=0):
+            self.got[(k, kind)] = np.asarray(v)
+
+    good = {'a/kernel': np.zeros((2, 3), np.float32), 'a/bias': np.ones(3, np.float32), 'global_step': np.asarray(7)}
+    m = Stub()
+    ckpt.load_state_dict(m, good)
+    assert m.step == 7 and ('a/bias', 0) in m.got
+    with pytest.raises(ValueError, match='a/kernel'):
+        ckpt.load_state_dict(Stub(), dict(good, **{'a/kernel': np.zeros((3, 2), np.float32)}))
+    with pytest.raises(KeyError, match='unexpected'):
+        ckpt.load_state_dict(Stub(), dict(good, stray=np.zeros(1)))
+    with pytest.raises(KeyError, match='missing'):
+        ckpt.load_state_dict(Stub(), {'a/kernel': good['a/kernel']})
+    m = Stub()
+    ckpt.load_state_dict(m, {'a/kernel': good['a/kernel']}, strict=False)      # partial 'infer' restore
+    assert list(m.got) == [('a/kernel', 0)]
