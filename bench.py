@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 CFG = dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 B, S = 256, 64
 PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA = 2500.0    # TFLOP/s dense (same table)
+PMC_TAG = 'r02'            # the committed rocprofv3 --pmc passes `traffic` / `mfma_busy` are read from
 
 
 def host_cores():
@@ -44,7 +46,9 @@ def host_cores():
     return n
 
 
-def cpu_baseline(sample_b=64, steps=6):       # ~10 s of host work at ~45 sentences/s
+def cpu_baseline(steps=5, warmups=2):
+    """the torch-CPU restatement on the SAME full batch (256 x 64, FULL), fwd + bwd + Adam, 2 warm-ups then
+    `steps` timed steps on the cores this process may use (~35 s on the GPU box's 16-core share)"""
     import numpy as np
     import torch
     from argsim_amd import synth
@@ -56,18 +60,55 @@ def cpu_baseline(sample_b=64, steps=6):       # ~10 s of host work at ~45 senten
     P = vn.init_params(cfg, 0)
     tr = vt.CpuTrainer(P, cfg)
     tr.step = 20000
-    ids = synth.batch(sample_b, S, CFG['dim_tgt'], seed=0)
+    b, s = 256, 64
+    ids = synth.batch(b, s, CFG['dim_tgt'], seed=0)
     rng = np.random.default_rng(0)
-    keep = (rng.random((S, sample_b)) < 0.88).astype(np.int32)
-    eps = rng.standard_normal((sample_b, CFG['dim_rep'])).astype(np.float32)
-    tr.train_step(ids, ids, keep, eps)            # warm-up
+    keep = (rng.random((s, b)) < 0.88).astype(np.int32)
+    eps = rng.standard_normal((b, CFG['dim_rep'])).astype(np.float32)
+    for _ in range(warmups):
+        tr.train_step(ids, ids, keep, eps)
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.train_step(ids, ids, keep, eps)
     dt = time.perf_counter() - t0
-    return dict(value=sample_b * steps / dt, unit="sentences/sec", cores=cores, kind="port",
-                sample="%d timed ELBO steps (fwd+bwd+Adam, fp32 torch-CPU restatement) on %d of the %d rows, seq %d"
-                       % (steps, sample_b, B, S))
+    return dict(value=b * steps / dt, unit="sentences/sec", cores=cores, kind="port",
+                sample="%d timed ELBO steps after %d warm-ups (fwd+bwd+Adam, fp32 torch-CPU restatement of model.py; TensorFlow is "
+                       "absent and CudnnGRU is GPU-only) on the full %d x %d FULL batch of the headline workload" % (steps, warmups, b, s))
+
+
+def side_config(label, dtype, b, s, steps=3, warmup=2):
+    """one of the other BASELINE configurations on this GPU, a few steps, with its kernel-class split (HIP events)"""
+    import torch
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', device=torch.cuda.current_device(), seed=0, dtype=dtype, **CFG)
+    m.step = 20000
+    ids = torch.as_tensor(synth.batch(b, s, CFG['dim_tgt'], seed=0)).to(m.device)
+    for i in range(warmup):
+        m.train_step(ids, ids, seed=i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m.train_step(ids, ids, seed=warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    m.set_option('timing', 1)                      # one more, stamped step for the class split
+    m.train_step(ids, ids, seed=99)
+    tm = m.timing_collect()
+    m.set_option('timing', 0)
+    losses = m.losses()
+    assert all(x == x and abs(x) < 1e6 for x in losses), losses
+    peak = {'f32': PEAK_F32_MFMA, 'bf16': PEAK_BF16_MFMA, 'f32s': PEAK_BF16_MFMA / 6.0}[dtype]
+    out = {"workload": label, "dtype": dtype, "batch": b, "seq_len": s, "steps": steps, "warmup": warmup,
+           "value": b / dt, "unit": "sentences/sec", "ms_per_step": 1e3 * dt, "loss": losses[2],
+           "classes": {k: {"ms_per_step": v[0], "launches_per_step": v[1], "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0)}
+                       for k, v in tm.items()},
+           "gemm_frac_of_peak": (tm['gemm'][2] / (tm['gemm'][0] * 1e-3) / 1e12 / peak) if tm['gemm'][0] > 0 else None,
+           "gemm_peak_tflops": peak}
+    m.close()
+    del m, ids
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -85,6 +126,7 @@ def main():
     ap.add_argument('--seq', type=int, default=S, help="sequence length (default 64; 128 = configs[2])")
     ap.add_argument('--ragged', action='store_true', help="RAGGED synthetic set (LogNormal lengths, eos padded) instead of FULL; not the headline")
     ap.add_argument('--no-alt', action='store_true', help="skip the extra f32s leg (same workload with the split-bf16 fp32 GEMMs)")
+    ap.add_argument('--no-configs', action='store_true', help="skip the 'configs' object (BASELINE configs[2] and configs[3]'s per-GPU load, a few steps each)")
     ap.add_argument('--gru-stagger', type=int, default=0)
     ap.add_argument('--gru-turn', type=int, default=-1, help="team kernels: 0 free arbitration, 1 cyclic MFMA windows, 2 FIFO MFMA windows")
     ap.add_argument('--gru-item', type=int, default=-1, help="forward GRU kernel: 0 generic, 1 item pipeline, 2 four-team LDS-weight kernel")
@@ -200,17 +242,21 @@ def main():
             total_ms = 1e3 * dt * nst / A.steps            # wall time of the stamped steps
             name, (ms, n, fl) = max(tm.items(), key=lambda kv: kv[1][0])
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic = None
-            try:   # HBM bytes per launch of this kernel class from the separate rocprofv3 --pmc passes
-                   # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; scripts/summarize_profile.py)
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary%s.json' % ('' if A.dtype == 'f32' else '_' + A.dtype))))
+            traffic = mfma_busy = None
+            pmc_file = 'profiles/%s%s_pmc_summary.json' % (PMC_TAG, '' if A.dtype == 'f32' else '_' + A.dtype)
+            try:   # per launch of this kernel class, from the COMMITTED rocprofv3 --pmc passes of this same command
+                   # (scripts/profile_round.sh + summarize_profile.py; FETCH_SIZE doubled per the gfx950 rule): not a
+                   # measurement of this run
+                pm = json.load(open(os.path.join(ROOT, pmc_file)))
                 if name == 'gemm':
                     traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
+                    mfma_busy = pm['gemm_class'].get('mfma_busy')
             except Exception:
                 pass
-            peak = PEAK_F32_MFMA if (A.dtype == 'f32' or name != 'gemm') else (2500.0 if A.dtype == 'bf16' else 2500.0 / 6.0)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                               "frac": ach / peak, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch, from the committed PMC passes %s (not measured by this run)" % pmc_file,
+                               "mfma_busy": mfma_busy,
                                "flops_per_launch": fl / max(n, 1),
                                "launches_per_step": n / nst, "avg_launch_ms": ms / max(n, 1), "stamped_steps": nst,
                                "share_of_step": ms / total_ms,
@@ -238,6 +284,17 @@ def main():
             out["f32s"] = {"value": B * A.steps / dt2, "unit": "sentences/sec", "ms_per_step": 1e3 * dt2 / A.steps, "loss": l2[2],
                            "dtype": "f32 in / f32 accumulate / f32 out; GEMM operands split into 3 x bf16 in registers, 6 partial "
                                     "products on v_mfma_f32_32x32x16_bf16 (VAE(dtype='f32s'), compute_dtype 2)"}
+        if world == 1 and headline and A.dtype == 'f32' and not A.no_configs:
+            # the other single-GPU BASELINE configurations, labelled; never the headline value
+            try:
+                del m2
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            out["configs"] = {
+                "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 GEMM operands (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128),
+                "configs[3]/gpu": side_config("BASELINE configs[3] per-GPU load: fp32, batch 1024 (global 8192 over 8 GPUs), seq_len 64; the all-reduce is not part of it", 'f32', 1024, 64),
+            }
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -13,11 +13,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from helpers import CASES, make_case  # noqa: E402
+from helpers import CASES, PROD_CASES, make_case  # noqa: E402
 from oracle import vae_numpy as vn  # noqa: E402
 from oracle import vae_torch as vt  # noqa: E402
 
-for name in CASES:
+for name in (CASES if len(sys.argv) == 1 else [n for n in sys.argv[1:] if n in CASES]):
     cfg, P, ids, keep, eps = make_case(name)
     o = vn.forward(P, cfg, ids, ids, 'train', 20000, keep, eps)
     out = dict(ids=ids, keep=keep, eps=eps, loss=o['loss'], loss_gen=o['loss_gen'], loss_kld=o['loss_kld'],
@@ -28,3 +28,24 @@ for name in CASES:
             out['gnorm/' + k] = np.linalg.norm(g)
     np.savez_compressed(os.path.join(HERE, 'oracle_%s.npz' % name), **out)
     print(name, float(o['loss']))
+
+
+def probe(name, shape):
+    """a fixed pseudo-random direction per variable: <grad, probe> pins more than the norm does"""
+    import zlib
+    return np.random.default_rng(zlib.crc32(name.encode())).standard_normal(shape)
+
+
+# production geometry: only reduced outputs (loss, mu, per-variable gradient norm and one projection each)
+for name in (sys.argv[1:] or PROD_CASES):
+    if name not in PROD_CASES:
+        continue
+    cfg, P, ids, keep, eps = make_case(name)
+    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, 20000, keep, eps)
+    o = vn.forward(P, cfg, ids, ids, 'valid')
+    out = dict(ids=ids, keep=keep, eps=eps, loss=outs['loss'], loss_gen=outs['loss_gen'], loss_kld=outs['loss_kld'], mu=o['mu'], lv=o['lv'])
+    for k, g in grads.items():
+        out['gnorm/' + k] = np.linalg.norm(g)
+        out['gdot/' + k] = float((g * probe(k, g.shape)).sum())
+    np.savez_compressed(os.path.join(HERE, 'oracle_%s.npz' % name), **out)
+    print(name, float(outs['loss']), flush=True)

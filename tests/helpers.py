@@ -10,16 +10,27 @@ CASES = {
     'wide':  (dict(dim_tgt=512, dim_emb=256, dim_rep=64, rnn_layers=2), 20, 9, None),
     'full2': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 2, 64, [64, 23]),
 }
+# production geometry (D = 512, V = 8192, B = 64: one full 64-row block per GRU workgroup, so the LDS-weight team
+# kernels, the fast-staging and split-K GEMM paths run).  Too large for the live float64 oracle inside a test:
+# compared with committed reduced fixtures only (tests/golden/make_oracle_golden.py).
+PROD_CASES = {
+    'prod64':  (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 64, 64, 'ragged'),
+    'prod128': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 64, 128, 'ragged'),
+}
 
 
 def make_case(name, seed=0, pad=2, bias_scale=0.1):
-    kw, B, S, lens = CASES[name]
+    kw, B, S, lens = (CASES.get(name) or PROD_CASES[name])
     cfg = vn.make_cfg(**kw)
     rng = np.random.default_rng(seed + 17)
     V, R = cfg['dim_tgt'], cfg['dim_rep']
     ids = np.full((B, S + pad), cfg['eos'], np.int32)
     if lens is None:
         lens = [S] * B
+    elif isinstance(lens, str):        # 'ragged': a few full rows, a length-1 row, the rest uniform in [2, S]
+        lens = rng.integers(2, S + 1, B)
+        lens[[0, B // 2]] = S
+        lens[1] = 1
     for b, n in enumerate(lens):
         ids[b, :n] = rng.integers(3, V, n)
     smax = max(lens)
