@@ -534,6 +534,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
         fire_hook(h, 2 + L + (L - 1 - i));
+        if (i == 0) hook_flush(h);         // no persistent launch follows: announce now, beside the embedding scatter-adds
     }
     // embedding: gather gradients on top of the logits term
     AV_CHECK(embed_scatter_add(st, G + h->oE, w.src_tm, w.demb_src, rs, D, V));

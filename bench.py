@@ -253,6 +253,7 @@ def main():
                     mfma_busy = pm['gemm_class'].get('mfma_busy')
             except Exception:
                 pass
+            peak = PEAK_F32_MFMA if (A.dtype == 'f32' or name != 'gemm') else (PEAK_BF16_MFMA if A.dtype == 'bf16' else PEAK_BF16_MFMA / 6.0)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch, from the committed PMC passes %s (not measured by this run)" % pmc_file,

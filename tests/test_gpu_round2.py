@@ -212,7 +212,9 @@ def test_rank_keys_give_each_shard_its_own_draws(tmp_path):
         b.train_step(ids, ids, seed=rank_seed(key, 0))
         c.train_step(ids, ids, seed=rank_seed(key, 1))                         # what rank 1 would have drawn
         la, lb, lc = a.losses(), b.losses(), c.losses()
-        assert la == lb and la[0] != lc[0] and la[1] == lc[1]                  # KL is deterministic given mu, lv
+        # (the data-parallel call scales by 1/N_global passed in, the plain call by its own N: last-bit differences)
+        assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]) and abs(la[0] - lc[0]) > 1e-4 * abs(lc[0])
+        assert abs(la[1] - lc[1]) <= 1e-6 * abs(lc[1])                         # KL depends on mu, lv only: no draw in it
         assert float((a.params - b.params).abs().max()) <= 1e-6
     finally:
         dist.destroy_process_group()
