@@ -637,45 +637,27 @@ __device__ __forceinline__ void team_barrier(unsigned* word, unsigned target)
 }
 
 
-// MFMA turnstile of the team kernels.  Four chains share a CU's four matrix pipes and every chain's K split puts one
-// wave on each SIMD; left to the hardware arbiter the four SIMDs serve the teams in different orders and a team's
-// partial sums wait for the slowest SIMD at the team barrier (~2 us per step).  With the turnstile exactly one team
-// issues MFMAs at a time, on all four SIMDs together: the window of a team is its 96 MFMAs per wave back to back,
-// the other teams' exchange waits, operand loads and gate math run beside it.
-//   words: [0] completed wave-windows  [1] next ticket  [2..5] per-team ready count  [6..9] per-team ticket (+1)
-struct Turnstile {
-    unsigned* w; int mode; unsigned last = 0;
-    __device__ __forceinline__ void enter(int team, unsigned slot)
-    {
-        if (mode == 0) return;
-        unsigned first;
-        if (mode == 1) first = 4u * slot;                           // cyclic: slot = 4 * step + team
-        else {
-            unsigned old = 0;
-            if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(w + 2 + team, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if ((old & 3u) == 3u && (threadIdx.x & 63) == 0) {       // the team's last wave draws the ticket
-                const unsigned t = __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(w + 6 + team, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            unsigned tk;
-            while ((tk = __hip_atomic_load(w + 6 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == last) __builtin_amdgcn_s_sleep(1);
-            last = tk;
-            first = 4u * (tk - 1u);
-        }
-        while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void leave()
-    {
-        if (mode == 0) return;
-        __builtin_amdgcn_sched_barrier(0);
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-};
+// blockIdx -> (chain group, hidden tile): the grid is C x 32 workgroups, C <= 8 chain groups.  A chain group is a job
+// plus the 64-row blocks slot, slot + cpj, ... of that job (cpj = chain groups per job); the 32 workgroups of a chain
+// group exchange with each other and share blockIdx % C (one XCD under round-robin dispatch when C = 8; speed only).
+struct TeamMap { int cid, ht, jb, slot, cpj, nrb; };
+__device__ __forceinline__ TeamMap team_map(const GruArgs& a)
+{
+    TeamMap m;
+    const int C = gridDim.x / 32;
+    m.cid = blockIdx.x % C; m.ht = blockIdx.x / C;
+    m.cpj = C / a.njobs;
+    m.jb = m.cid / m.cpj; m.slot = m.cid % m.cpj;
+    m.nrb = (a.B / 64) / m.cpj;
+    return m;
+}
 
-template <bool DIAG>
+// PIPE (several row blocks per workgroup): the A fragment of an item is put in flight behind the MFMAs of the item
+// before it (another chain, stored an item ago) and only verified at its own item; !PIPE (one row block: the next
+// item depends on this one's own stores): polled and loaded at the top of the item.  Two instantiations so that each
+// has ONE load site inside the loop -- with two, the register allocator parks the prefetched fragment in other
+// registers and copies it at the loop edge, which waits for the loads exactly where they were meant to overlap.
+template <bool DIAG, bool PIPE>
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
     const int ab = DIAG ? a.ablate : 0;                     // timing experiments / stamps: diagnostic instantiation only
@@ -689,15 +671,10 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int team = wave >> 2, wk = wave & 3;
     const int n = lane & 15, kh = lane >> 4;
-    // blockIdx -> (row block of 64, job) on the XCD axis, hidden tile on the other: the 32 workgroups that
-    // exchange with each other share blockIdx % 8 (one XCD under round-robin dispatch; speed only)
-    const int nrb = a.B / 64;                               // row blocks per job
-    const int chains = a.njobs * nrb;                       // (job, row block) pairs, <= 8
-    const int cid = blockIdx.x % chains, ht = blockIdx.x / chains;
-    const int jb = cid / nrb, rblk = cid % nrb;
-    const GruJob& J = a.job[jb];
+    const TeamMap tm = team_map(a);
+    const int cid = tm.cid, ht = tm.ht;
+    const GruJob& J = a.job[tm.jb];
     const int B = a.B;
-    const int row0 = rblk * 64 + team * 16;                 // this team's 16 rows
 
     // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
     for (int blk = wave; blk < 96; blk += 16) {
@@ -705,7 +682,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         const float4 v = *reinterpret_cast<const float4*>(J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 16 * q + 4 * kh);
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = v;
     }
-    if (tid < 2 * kTeams + 10) sync[tid] = 0u;              // [0..3] team barrier counters, [4..7] exchange-ready epochs, [8..17] turnstile
+    if (tid < 2 * kTeams) sync[tid] = 0u;                   // [0..3] team barrier counters, [4..7] exchange-ready epochs
     const int tt = tid & 255;                               // thread inside the team
     const int gn = tt & 15, gr = tt >> 4;
     const int j = ht * 16 + gn;
@@ -713,17 +690,15 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
     const int own_wk = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
-    const int len_a = J.reverse ? a.lens[row0 + n] : 0, len_g = J.reverse ? a.lens[row0 + gr] : 0;
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (4 * 3 * 256);
     float* thps = hps + team * 256;
     unsigned* tsync = sync + team;
+    unsigned* ready = sync + kTeams + team;
     unsigned epoch = 0;
-    Turnstile ts{sync + 2 * kTeams, a.turn};
     // de-phase the four chains: identical chains started together stay in lock step and collide on the matrix
     // pipe; an initial offset of a fraction of a step per team persists (equal periods)
-    for (int i = 0; i < team * a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     // one consistent arbitration order on all four SIMDs: a team's K-split partners sit on different SIMDs and
     // meet at the team barrier, so if every SIMD serves the teams in the same order the partners finish together
     // (otherwise the barrier pays the arbitration skew, measured at 2-3 us per step)
@@ -735,52 +710,82 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     }
 
     const bool stamp = (ab & 128) != 0;                        // diagnostic phase stamps (never in timed runs)
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TSTAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
+    // Work item = (step p, row block r).  With more than one row block per workgroup a team's next item belongs to
+    // another chain, whose operands every producer stored a whole item ago: the exchange latency of one chain hides
+    // behind the MFMAs of the others (software pipelining over the row blocks; time is then linear in rows at the
+    // matrix-pipe rate instead of at the chain latency).
+    unsigned it = 0;                                          // items done so far (monotonic; LDS epochs derive from it)
+    u32x4 ra[8];
+    auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first 16-byte piece
+        const int row = row0 + n;
+        const unsigned o = (p == 0) ? (unsigned)((size_t)row * D * 4)
+                                    : (unsigned)((((size_t)pos_map(p - 1, len_a, J.reverse) * B + row) * a.ldh) * 4);
+        return o + (wk * WK + 4 * kh) * 4;
+    };
+    auto next_frag = [&](int p2, int r2, int len2) __attribute__((always_inline)) {   // PIPE: issue (or zero) the fragment of item (p2, r2)
+        if (p2 > 0 || J.h0 != nullptr) {
+            const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+            frag_issue<8>(ra, (p2 == 0) ? rs_h0 : rs_hs, a_offset(p2, row2, len2));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    // sequence lengths of the rows this lane touches in the current item (A rows: n, gate rows: tid's row)
+    int len_a = J.reverse ? a.lens[tm.slot * 64 + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * 64 + team * 16 + (tid & 255) / 16] : 0;
+    if constexpr (PIPE) next_frag(a.p_begin, 0, len_a);
     for (int p = a.p_begin; p < a.p_end; ++p) {
+      for (int r = 0; r < tm.nrb; ++r, ++it) {
         TSTAMP(5);
+        const int row0 = (tm.slot + r * tm.cpj) * 64 + team * 16;     // this team's 16 rows of row block r
         const bool poll = p > a.p_begin && !(ab & 16);            // ablate 16: timing experiment, wrong results
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
         const float* gp = J.gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
         const float gi0 = gp[0], gi1 = gp[1], gi2 = gp[2];
+        // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
+        const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p + 1;
+        int len2 = len_a, len2g = len_g;
+        if constexpr (PIPE) {
+            if (J.reverse && p2 < a.p_end) {
+                const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+                len2 = a.lens[row2 + n]; len2g = a.lens[row2 + gr];
+            }
+        }
         // (2) A operand: this wave's K quarter of the team's 16 rows
-        u32x4 ra[8];
         const bool have = p > 0 || J.h0 != nullptr;
         if (have) {
-            const int row = row0 + n;
-            unsigned aoff = (p == 0) ? (unsigned)((size_t)row * D * 4)
-                                     : (unsigned)((((size_t)pos_map(p - 1, len_a, J.reverse) * B + row) * a.ldh) * 4);
-            aoff += (wk * WK + 4 * kh) * 4;
+            const unsigned aoff = a_offset(p, row0, len_a);
             const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
-            if (poll) {
-                // ONE wave per team polls the exchange and releases its three K-split partners through an LDS
-                // word: four independent polls would leave the partners up to a poll period (~1 us) apart and
-                // the team barrier pays that skew.  The probe (lane l reads the last element producer l&31
-                // stores for these 16 rows: one 256-byte request per poll) is a start signal only; every wave
-                // still verifies its own fragment dword by dword below.
-                unsigned* ready = sync + kTeams + team;
-                if (wk == 0) {
-                    const int prow = row0 + 15;
-                    const int plen = J.reverse ? a.lens[prow] : 0;
-                    const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
-                    SpinGuard sg;
-                    while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
-                    if (lane == 0) __hip_atomic_store(ready, (unsigned)(p - a.p_begin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(p - a.p_begin)) __builtin_amdgcn_s_sleep(1);
+            if constexpr (!PIPE) {
+                if (poll) {
+                    // ONE wave per team polls the exchange and releases its three K-split partners through an LDS
+                    // word: four independent polls would leave the partners up to a poll period (~1 us) apart and
+                    // the team barrier pays that skew.  The probe (lane l reads the last element producer l&31
+                    // stores for these 16 rows: one 256-byte request per poll) is a start signal only; every wave
+                    // still verifies its own fragment dword by dword below.
+                    if (wk == 0) {
+                        const int prow = row0 + 15;
+                        const int plen = J.reverse ? a.lens[prow] : 0;
+                        const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
+                        SpinGuard sg;
+                        while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                        if (lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
+                    }
                 }
+                frag_issue<8>(ra, rs, aoff);
             }
-            frag_issue<8>(ra, rs, aoff);
             if (poll) frag_ensure<8>(ra, rs, aoff, a.err);
-        } else {
+        } else if constexpr (!PIPE) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
         TSTAMP(0);
-        ts.enter(team, 4u * (unsigned)(p - a.p_begin) + (unsigned)team);
-        TSTAMP(4);
         // (3) MFMAs, B fragments from LDS
         f32x4 acc[3];
 #pragma unroll
@@ -797,11 +802,11 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 for (int gate = 0; gate < 3; ++gate)
                     acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ra[q][e]), b[gate][e], acc[gate], 0, 0, 0);
         }
-        ts.leave();
         TSTAMP(1);
-        // every wave of the team has finished READING the previous step's partial sums (second team barrier
-        // of that step, taken here so that it costs nothing), then publish this step's
-        if (p > a.p_begin) { epoch += 4; team_barrier(tsync, epoch); }
+        // every wave of the team has finished READING the previous item's partial sums (second team barrier
+        // of that item, taken here so that it costs nothing), then publish this item's
+        if (it > 0) { epoch += 4; team_barrier(tsync, epoch); }
+        TSTAMP(6);
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
             *reinterpret_cast<f32x4*>(tpart + (wk * 3 + gate) * 256 + lane * 4) = acc[gate];
@@ -810,6 +815,18 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             for (int q = 0; q < 8; ++q)
                 if (q == own_q) *reinterpret_cast<u32x4*>(thps + n * 16 + 4 * kh) = ra[q];
         }
+        // (3b) PIPE: the NEXT item is another chain, whose operand every producer stored an item ago.  Its loads go in
+        // flight now, into the registers the MFMAs have just released, and land behind the team barrier and the gate
+        // math (unverified here: the sentinel check of (2) still decides).
+        if constexpr (PIPE) {
+            // (every load issued so far is retired HERE, on purpose: hipcc's waitcnt insertion merges the two sides of
+            //  the branch below conservatively and would otherwise wait for the new fragment at the first use of gi)
+            asm volatile("" :: "v"(gi0), "v"(gi1), "v"(gi2), "v"(len2), "v"(len2g));
+            __builtin_amdgcn_sched_barrier(0);
+            if (p2 < a.p_end) next_frag(p2, r2, len2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TSTAMP(7);
         epoch += 4; team_barrier(tsync, epoch);
         TSTAMP(2);
         // (4) gate math: the team's 256 threads, one element each; exchanged store first
@@ -821,18 +838,20 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 gh[gate] = bR[gate] + ((tpart[(0 * 3 + gate) * 256 + pidx] + tpart[(1 * 3 + gate) * 256 + pidx]) +
                                        (tpart[(2 * 3 + gate) * 256 + pidx] + tpart[(3 * 3 + gate) * 256 + pidx]));
             const float hprev = thps[gr * 16 + gn];
-            const float r = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r * gh[2]);
+            const float r_ = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r_ * gh[2]);
             const float hnew = (1.f - u) * nn + u * hprev;
             const size_t rix = (size_t)gpos * B + grow;
             float* hdst = J.hs + rix * a.ldh + j;
             if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
-            if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r, u, nn, gh[2]);
+            if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r_, u, nn, gh[2]);
             if (J.hp) J.hp[rix * D + j] = hprev;
         }
+        len_a = len2; len_g = len2g;
         TSTAMP(3);
+      }
     }
     if (stamp && (tid & 255) == 0 && a.stamps) {
-        for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, ph[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, ph[i]);
         atomicAdd(a.stamps + 8, (unsigned long long)(a.p_end - a.p_begin));
         atomicAdd(a.stamps + 10, 1ULL);
     }
@@ -1106,14 +1125,14 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 
 // ------------------------------------------------------------------------------ backward, D = 512, four teams per CU
 // The LDS-weight form of the backward step (the forward's gru_fwd_team_kernel is its model): ONE workgroup of 16
-// waves owns a (job, 64-row block, 16-unit slice); its 1536 x 16 slice of R' (the B operand of dH_prev = dgh R)
-// lives in LDS in MFMA B-fragment order (96 KB, one ds_read_b128 per four MFMA steps) and is shared by FOUR teams
-// of 4 waves; every team runs an independent 16-row chain.  The register form above holds the slice in 96 VGPRs,
-// which caps it at two chains per CU; here four chains per CU keep twice the dgh bytes in flight per SIMD.  A
-// operand: the same hand-counted sc1 piece stream with a running-max sentinel check and a one-instruction probe
-// as the D = 512 path above, with a ring of TWO 24-register pieces (128-register budget at 4 waves per SIMD).
-// Encoder layers only (no dh0 tail).  Teams synchronise through monotonic LDS counters, never s_barrier.
-template <int NB>
+// waves owns a (job, 16-unit slice) and one or more 64-row blocks; its 1536 x 16 slice of R' (the B operand of
+// dH_prev = dgh R) lives in LDS in MFMA B-fragment order (96 KB, one ds_read_b128 per four MFMA steps) and is shared by
+// FOUR teams of 4 waves; every team runs independent 16-row chains (one per row block, interleaved item by item as in
+// the forward).  A operand: the hand-counted sc1 piece stream with a running-max sentinel check and a one-instruction
+// probe of the register-form D = 512 path above, with a ring of NB 24-register pieces (128-register budget at 4 waves
+// per SIMD) whose first NB pieces are in flight before the MFMAs start.  A job with dh0 (decoder layers) gets the
+// tail item p = -1: dh0 = carry + dgh_0 R.  Teams synchronise through monotonic LDS counters, never s_barrier.
+template <int NB, bool PIPE>          // PIPE: several row blocks per workgroup (see the forward)
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
     constexpr int D = 512, HT = 32, NH = 4, PQ = 6;
@@ -1126,12 +1145,10 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int team = wave >> 2, wk = wave & 3;
     const int n = lane & 15, kh = lane >> 4;
-    const int nrb = a.B / 64, chains = a.njobs * nrb;
-    const int cid = blockIdx.x % chains, ht = blockIdx.x / chains;
-    const int jb = cid / nrb, rblk = cid % nrb;
-    const GruJob& J = a.job[jb];
+    const TeamMap tm = team_map(a);
+    const int cid = tm.cid, ht = tm.ht;
+    const GruJob& J = a.job[tm.jb];
     const int B = a.B, S = a.S;
-    const int row0 = rblk * 64 + team * 16;
 
     // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
     for (int blk = wave; blk < 96; blk += 16) {
@@ -1139,17 +1156,14 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         const float* rp = J.R + (size_t)(wq * 384 + 16 * ks4 + 4 * kh) * D + ht * 16 + n;
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[D], rp[2 * D], rp[3 * D]);
     }
-    if (tid < kTeams + 10) sync[tid] = 0u;                  // [0..3] team barrier counters, [4..13] turnstile
+    if (tid < kTeams) sync[tid] = 0u;
     if (tid < 64) red[tid] = 0.f;
     const int tt = tid & 255, gn = tt & 15, gr = tt >> 4;
     const int j = ht * 16 + gn;
-    const int len_a = J.reverse ? a.lens[row0 + n] : 0, len_g = J.reverse ? a.lens[row0 + gr] : 0;
-    const int len_p = J.reverse ? a.lens[row0 + 15] : 0;
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (4 * 256);
     unsigned* tsync = sync + team;
     unsigned epoch = 0;
-    Turnstile ts{sync + kTeams, a.turn};
     {
         const int tq = __builtin_amdgcn_readfirstlane(team);      // one arbitration order on all four SIMDs (see the forward)
         if (tq == 0) __builtin_amdgcn_s_setprio(3);
@@ -1158,41 +1172,83 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     }
     const unsigned long long pa = (unsigned long long)J.dgh;
     const i32x4 srd = {(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
-    const int grow = row0 + gr;
     float sb_r = 0.f, sb_u = 0.f, sb_n = 0.f, sb_nr = 0.f;
+    const bool want_dh0 = (J.dh0 != nullptr) && a.p_begin == 0;
+    const int p_last = want_dh0 ? -1 : a.p_begin;             // p == -1: only dh0 = carry + dgh_0 R'
     int done = 0;
-    for (int p = a.p_end - 1; p >= a.p_begin; --p, ++done) {
+    unsigned it = 0;
+    u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
+    const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
+    auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
+        return (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * 384) * 4) + 16 * kh;
+    };
+    auto issue_piece = [&](int piece, u32x4 (&dst)[PQ], unsigned vo) __attribute__((always_inline)) {
+        if (piece == 0) asm_issue6<0>(dst, vo, srd);
+        if (piece == 1) asm_issue6<384>(dst, vo, srd);
+        if (piece == 2) asm_issue6<768>(dst, vo, srd);
+        if (piece == 3) asm_issue6<1152>(dst, vo, srd);
+    };
+    // the first NB pieces go in flight BEFORE the item's MFMAs, the rest behind the MFMAs of the piece whose
+    // registers they reuse
+    auto head = [&](unsigned vo) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s0 = 0; s0 < NB && s0 < NH; ++s0) issue_piece(s0, hv[s0], vo);
+    };
+    // PIPE: the first NB pieces of item (p2, r2) as compiler-visible loads (not the inline-asm form): they stay pending
+    // across the barrier, the gate math and the loop edge, so the compiler itself must keep their destination
+    // registers intact and wait for them before the pass touches hv; beside the asm loads its counted waits can only
+    // over-wait
+    auto next_head = [&](int p2, int r2, int len2) __attribute__((always_inline)) {
+        if (p2 + 1 < S) {
+            const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+            const unsigned vo2 = a_offset(p2, row2, len2);
+#pragma unroll
+            for (int s0 = 0; s0 < NB && s0 < NH; ++s0)
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) hv[s0][q] = load16_sc1(rs_dgh, vo2 + 384u * s0 + 64u * q);
+        }
+    };
+    int len_a = J.reverse ? a.lens[tm.slot * 64 + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * 64 + team * 16 + gr] : 0;
+    if constexpr (PIPE) next_head(a.p_end - 1, 0, len_a);
+    for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
+      for (int r = 0; r < tm.nrb; ++r, ++it) {
+        const int row0 = (tm.slot + r * tm.cpj) * 64 + team * 16;
+        const int grow = row0 + gr;
         const bool have_next = p + 1 < S;
         const bool poll = done > 0;
+        // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
+        const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p - 1;
+        int len2 = len_a, len2g = len_g;
+        if constexpr (PIPE) {
+            if (J.reverse && p2 >= p_last) {
+                const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+                len2 = a.lens[row2 + n]; len2g = a.lens[row2 + gr];
+            }
+        }
         // (1) exchange-independent loads of the gate phase
-        const size_t rix = (size_t)pos_map(p, len_g, J.reverse) * B + grow;
-        const float4 sv = *reinterpret_cast<const float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4);
-        const float s_hp = J.hp[rix * D + j];
-        const float s_do = J.dh_out ? J.dh_out[rix * a.ldh + j] : 0.f;
+        const size_t rix = (size_t)pos_map(p < 0 ? 0 : p, len_g, J.reverse) * B + grow;
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
+        if (p >= 0) {
+            sv = *reinterpret_cast<const float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4);
+            s_hp = J.hp[rix * D + j];
+            s_do = J.dh_out ? J.dh_out[rix * a.ldh + j] : 0.f;
+        }
+        // dH_{p+1} u_{p+1} of this (row, unit): written by this same thread one step ago
+        // (PIPE: fetched here, ahead of the next item's operand loads -- memory returns in order, so a load issued
+        //  behind them would wait for them)
+        float* carryp = J.carry + (size_t)grow * D + j;
+        float s_carry = 0.f;
+        if constexpr (PIPE) { if (have_next) s_carry = *carryp; }
         // (2)+(3) A operand = dgh_{p+1} of the team's 16 rows, this wave's K quarter, in four 96-float pieces
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         if (have_next) {
-            const unsigned voff = (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * 384) * 4) + 16 * kh;
-            u32x4 hv[NB][PQ];
+            const unsigned voff = a_offset(p, row0, len_a);
             f32x4 acc[2];
-            auto issue_piece = [&](int piece, u32x4 (&dst)[PQ]) __attribute__((always_inline)) {
-                if (piece == 0) asm_issue6<0>(dst, voff, srd);
-                if (piece == 1) asm_issue6<384>(dst, voff, srd);
-                if (piece == 2) asm_issue6<768>(dst, voff, srd);
-                if (piece == 3) asm_issue6<1152>(dst, voff, srd);
-            };
-            // the first NB pieces go in flight BEFORE the team's MFMA window opens, the rest behind the MFMAs of the
-            // piece whose registers they reuse
-            auto head = [&]() __attribute__((always_inline)) {
-#pragma unroll
-                for (int s0 = 0; s0 < NB && s0 < NH; ++s0) issue_piece(s0, hv[s0]);
-            };
             auto pass = [&]() __attribute__((always_inline)) -> bool {
                 unsigned mx = 0u;
 #pragma unroll
                 for (int st = 0; st < NH; ++st) {
-                    constexpr int kIssuedMax = NH;
-                    const int issued = (NB + st < kIssuedMax) ? NB + st : kIssuedMax;      // pieces issued so far
+                    const int issued = (NB + st < NH) ? NB + st : NH;                       // pieces issued so far
                     const int younger = issued - 1 - st;                                    // still allowed in flight
                     if (younger == 2) asm_wait6<12>(hv[st % NB]);
                     else if (younger == 1) asm_wait6<6>(hv[st % NB]);
@@ -1209,57 +1265,67 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                         for (int e = 0; e < 4; ++e)
                             acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][q][e]), b[e], acc[e & 1], 0, 0, 0);
                     }
-                    if (st + NB < NH) issue_piece(st + NB, hv[st % NB]);
+                    if (st + NB < NH) issue_piece(st + NB, hv[st % NB], voff);
                 }
                 sum = acc[0] + acc[1];
                 return __any(mx == kSentinel);
             };
             auto probe = [&](SpinGuard& sg) __attribute__((always_inline)) {
                 // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
+                const int len_p = J.reverse ? a.lens[row0 + 15] : 0;
                 const float* pp = J.dgh + ((size_t)pos_map(p + 1, len_p, J.reverse) * B + row0 + 15) * a.ldg + (lane & 31) * 48 + 47;
                 while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
             };
             SpinGuard sg;
-            if (poll) probe(sg);
-            head();
-            ts.enter(team, 4u * (unsigned)done + (unsigned)team);
+            if constexpr (!PIPE) {
+                if (poll) probe(sg);
+                head(voff);
+            }
             for (;;) {
                 const bool bad = pass();
                 if (!poll || !bad || sg.expired(a.err)) break;
                 probe(sg);
-                head();
+                head(voff);
             }
-            ts.leave();
-        } else {
-            ts.enter(team, 4u * (unsigned)done + (unsigned)team);      // keeps the cyclic order dense
-            ts.leave();
         }
-        // every wave of the team has finished READING the previous step's partial sums, then publish this step's
-        if (done > 0) { epoch += 4; team_barrier(tsync, epoch); }
+        // PIPE: the next item is another chain whose dgh every producer stored an item ago: its first NB pieces go in
+        // flight now, behind the team barrier and the gate math (the pass still checks every dword)
+        if constexpr (PIPE) {
+            // (the loads of the gate phase are retired HERE, on purpose: see the forward)
+            asm volatile("" :: "v"(sv.x), "v"(sv.y), "v"(sv.z), "v"(sv.w), "v"(s_hp), "v"(s_do), "v"(s_carry), "v"(len2), "v"(len2g));
+            __builtin_amdgcn_sched_barrier(0);
+            if (p2 >= p_last) next_head(p2, r2, len2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every wave of the team has finished READING the previous item's partial sums, then publish this item's
+        if (it > 0) { epoch += 4; team_barrier(tsync, epoch); }
         *reinterpret_cast<f32x4*>(tpart + wk * 256 + lane * 4) = sum;
         epoch += 4; team_barrier(tsync, epoch);
         // (4) gate derivatives: the team's 256 threads, one (row, unit) each; exchanged stores first
         {
             const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
             float carried = (tpart[pidx] + tpart[256 + pidx]) + (tpart[512 + pidx] + tpart[768 + pidx]);
-            float* carryp = J.carry + (size_t)grow * D + j;
-            if (have_next) carried += *carryp;
+            if constexpr (PIPE) carried += s_carry;
+            else if (have_next) carried += *carryp;
+            if (p < 0) { J.dh0[(size_t)grow * D + j] = carried; len_a = len2; len_g = len2g; continue; }
             const float dH = carried + s_do;
-            const float r = sv.x, u = sv.y, nn = sv.z;
+            const float r_ = sv.x, u = sv.y, nn = sv.z;
             const float dn = dH * (1.f - u) * (1.f - nn * nn);
             const float du = dH * (s_hp - nn) * u * (1.f - u);
-            const float dr = dn * sv.w * r * (1.f - r);
+            const float dr = dn * sv.w * r_ * (1.f - r_);
             float* dgh = J.dgh + rix * a.ldg + ht * 48 + gn * 3;
-            const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r);
+            const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
             if (fast) { dgh[0] = x0; dgh[1] = x1; dgh[2] = x2; }
             else { store4_sc1(dgh, x0); store4_sc1(dgh + 1, x1); store4_sc1(dgh + 2, x2); }
             *carryp = dH * u;
             float* dgi = J.dgi + rix * a.ldg + ht * 48 + gn * 3;
             dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
-            sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r;
+            sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
+        len_a = len2; len_g = len2g;
+      }
     }
-    // bias gradients: all 64 rows of the workgroup into LDS, then one atomic per (gate, unit)
+    // bias gradients: all rows of the workgroup into LDS, then one atomic per (gate, unit)
     if (J.dbW || J.dbR) {
         atomicAdd(&red[gn], sb_r); atomicAdd(&red[16 + gn], sb_u); atomicAdd(&red[32 + gn], sb_n); atomicAdd(&red[48 + gn], sb_nr);
         __syncthreads();
@@ -1377,8 +1443,21 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd)
     return e;
 }
 
+// geometry of the LDS-weight team kernels: C <= 8 chain groups x 32 hidden tiles = at most one 1024-thread workgroup
+// per CU; a chain group = one job and every (C / njobs)-th 64-row block of it.  Returns false where they do not apply.
+static bool team_geometry(const GruArgs& a, int* C)
+{
+    if (a.D != 512 || a.B % 64 || a.njobs > 2) return false;
+    const int nrbj = a.B / 64, np = a.njobs * nrbj;
+    if (np <= 8) { *C = np; return true; }
+    const int cpj = 8 / a.njobs;
+    if (nrbj % cpj) return false;
+    *C = 8;
+    return true;
+}
+
 template <class K>
-static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int lds_bytes)
+static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int lds_bytes, int C)
 {
     static const void* attr_done[8]; static int nattr = 0;
     const void* kp = reinterpret_cast<const void*>(kernel);
@@ -1389,7 +1468,7 @@ static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int ld
         if (e != hipSuccess) return e;
         if (nattr < 8) attr_done[nattr++] = kp;
     }
-    const int grid = a.njobs * (a.B / 64) * 32;
+    const int grid = C * 32;
     hipError_t e = resident(kernel, 1024, lds_bytes, grid);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds_bytes, st, a);
@@ -1401,15 +1480,19 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
         e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
-        // D = 512, two directions, B = 64 x (1..4): four independent 16-row teams per CU, weights in LDS
-        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && a.item_pipeline == 2) {
+        // D = 512, B a multiple of 64: four independent 16-row teams per CU, weights in LDS, the row blocks of a
+        // workgroup interleaved item by item.  A single job with fewer than 8 row blocks (a decoder layer at B = 256)
+        // would leave half the CUs idle: the register form below spreads it over all of them.
+        int C = 0;
+        if (team_geometry(a, &C) && (a.njobs == 2 || C == 8) && a.item_pipeline == 2) {
             const int lds_bytes = (4 * 3 * 8 * 256 + kTeams * 4 * 3 * 256 + kTeams * 256) * 4 + 128;
+            const bool pipe = a.njobs * (a.B / 64) > C;      // several row blocks per workgroup
 #ifdef AVAE_DIAG
             if (a.ablate) {
-                if (!(a.ablate & ~(16 | 128 | 256))) return launch_team(st, gru_fwd_team_kernel<true>, a, lds_bytes);
+                if (!(a.ablate & ~(16 | 128 | 256))) return pipe ? launch_team(st, gru_fwd_team_kernel<true, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<true, false>, a, lds_bytes, C);
             } else
 #endif
-            return launch_team(st, gru_fwd_team_kernel<false>, a, lds_bytes);
+            return pipe ? launch_team(st, gru_fwd_team_kernel<false, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false>, a, lds_bytes, C);
         }
         // benchmark geometry (D = 512, two full 16-row chunks per workgroup): software-pipelined kernel
         if (a.D == 512 && a.rows_per_group == 32 && a.B % 32 == 0 && a.G * 32 == a.B && !a.ablate && a.item_pipeline) {
@@ -1431,11 +1514,11 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
         e = prepare_exchange(st, a, false); if (e != hipSuccess) return e;
-        // D = 512, two directions without a dh0 tail (the encoder layers), B = 64 x (1..4), whole sequence in one launch
-        if (a.D == 512 && a.njobs == 2 && a.B % 64 == 0 && a.njobs * (a.B / 64) <= 8 && !a.ablate && a.item_pipeline == 2 &&
-            a.p_begin == 0 && a.p_end == a.S && !a.job[0].dh0 && !a.job[1].dh0) {
+        int C = 0;
+        if (team_geometry(a, &C) && (a.njobs == 2 || C == 8) && !a.ablate && a.item_pipeline == 2) {
             const int lds_bytes = (4 * 24 * 256 + kTeams * 4 * 256 + 64) * 4 + 64;
-            return launch_team(st, gru_bwd_team_kernel<2>, a, lds_bytes);
+            if (a.njobs * (a.B / 64) > C) return launch_team(st, gru_bwd_team_kernel<2, true>, a, lds_bytes, C);
+            return launch_team(st, gru_bwd_team_kernel<2, false>, a, lds_bytes, C);
         }
         return launch<false>(st, a, grid, true);
     }

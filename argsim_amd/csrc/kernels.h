@@ -75,7 +75,6 @@ struct GruArgs {
     int item_pipeline;    // 1: use the software-pipelined D = 512 forward kernel where its geometry applies
     int stagger;          // 1: delay the second half of the grid by ~half a step (co-resident chains de-phased)
     int force_slow;       // 1: never use the same-XCD L2 fast path
-    int turn;             // D = 512 team kernels: 0 = waves arbitrate freely, 1 = MFMA windows in cyclic team order, 2 = FIFO tickets
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);

@@ -128,7 +128,6 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help="skip the extra f32s leg (same workload with the split-bf16 fp32 GEMMs)")
     ap.add_argument('--no-configs', action='store_true', help="skip the 'configs' object (BASELINE configs[2] and configs[3]'s per-GPU load, a few steps each)")
     ap.add_argument('--gru-stagger', type=int, default=0)
-    ap.add_argument('--gru-turn', type=int, default=-1, help="team kernels: 0 free arbitration, 1 cyclic MFMA windows, 2 FIFO MFMA windows")
     ap.add_argument('--gru-item', type=int, default=-1, help="forward GRU kernel: 0 generic, 1 item pipeline, 2 four-team LDS-weight kernel")
     ap.add_argument('--gru-force-slow', action='store_true', help="never use the same-XCD L2 exchange path")
     ap.add_argument('--gru-ablate', type=int, default=0, help="timing experiments only (results are wrong)")
@@ -168,8 +167,6 @@ def main():
     model.set_option('gru_stagger', A.gru_stagger)
     if A.gru_item >= 0:
         model.set_option('gru_item', A.gru_item)
-    if A.gru_turn >= 0:
-        model.set_option('gru_turn', A.gru_turn)
     if A.gru_force_slow:
         model.set_option('gru_force_slow', 1)
     if A.gru_ablate:
