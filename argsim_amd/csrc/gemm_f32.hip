@@ -87,11 +87,12 @@ struct FastTile {
 // WM x WN waves (WM*WN = 4), each TM x TN MFMA tiles of 32x32: block tile BM = 32 WM TM, BN = 32 WN TN.
 // <2,2,2,2> = 128x128 is the workhorse; <1,4,1,1> = 32x128 serves thin row panels (M <= 512 and the
 // remainder rows of a tile count just above a multiple of 256) deterministically, without split-K.
-template <bool A_MC, bool B_NC, int WM, int WN, int TM, int TN, bool FAST = false>
+template <bool A_MC, bool B_NC, int WM, int WN, int TM, int TN, bool FAST = false, bool DB = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    constexpr int kStage = (BM + BN) * LDK;
+    __shared__ __attribute__((aligned(16))) float smem[kStage * (DB ? 2 : 1)];
     float* As = smem;
     float* Bs = smem + BM * LDK;
 
@@ -147,10 +148,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
     }
 
-    for (int k0 = kb; k0 < ke; k0 += BK) {
+    if (DB) {
         store_tile<A_MC, BM>(As, ra, tid);
         store_tile<B_NC, BN>(Bs, rb, tid);
         __syncthreads();
+    }
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        if (!DB) {
+            store_tile<A_MC, BM>(As, ra, tid);
+            store_tile<B_NC, BN>(Bs, rb, tid);
+            __syncthreads();
+        }
         if (k0 + BK < ke) {
             if (FAST) {
                 const int it = (k0 - kb) / BK + 1;
@@ -190,6 +198,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (DB) {
+            // the other stage: its readers passed the barrier that ended the previous K tile
+            As = (As == smem) ? smem + kStage : smem;
+            Bs = As + BM * LDK;
+            if (k0 + BK < ke) {
+                store_tile<A_MC, BM>(As, ra, tid);
+                store_tile<B_NC, BN>(Bs, rb, tid);
+            }
         }
         __syncthreads();
     }
@@ -231,6 +248,28 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
     const int k_per_wg = g.split_k > 1 ? (g.K + g.split_k - 1) / g.split_k : g.K;
     const bool fast = allow_fast && (a_mc ? (g.M % BM == 0) : (g.K % BK == 0 && g.dyn_kind != 2)) &&
                       (b_nc ? (g.N % BN == 0) : (g.K % BK == 0 && g.dyn_kind != 2)) && (a_mc || b_nc || k_per_wg >= 1536);
+    // Two launch forms of the 128x128 kernel.  Default: single LDS stage, two barriers per K tile, 3 workgroups per CU
+    // (768 slots).  Double-buffered: one barrier per K tile, 2 workgroups per CU (512 slots); measured 3-8 % slower at
+    // equal balance, but a tile count in (768, 1024] runs as ONE balanced round instead of a full round plus a round
+    // that leaves most slots empty (1024 tiles: 112 -> 130 TFLOP/s, gpurun_out/gb_db.log).
+    static const char* db_env = getenv("AVAE_F32_DB");
+    if constexpr (WM == 2 && WN == 2) {
+        const bool use_db = db_env ? atoi(db_env) != 0 : (g.split_k <= 1 && g.dyn_kind != 1 && tiles > 768 && tiles <= 1024);
+        if (use_db) {
+            if (fast) {
+                if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, g);
+                else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, g);
+                else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true, WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, g);
+                else                     hipLaunchKernelGGL((gemm_f32_kernel<true, false, WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, g);
+            } else {
+                if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, g);
+                else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, g);
+                else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true, WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, g);
+                else                     hipLaunchKernelGGL((gemm_f32_kernel<true, false, WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, g);
+            }
+            return;
+        }
+    }
     if (fast) {
         if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g);
         else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g);

@@ -140,6 +140,27 @@ struct AdamArgs { float* p; const float* g; float* m; float* v; int64_t n; float
                   const int* skip_if; };   // device word: non-zero -> the update is a no-op (GRU time-out flag)
 hipError_t adam_tf(hipStream_t st, const AdamArgs& a);
 
+// ---------------------------------------------------------------- greedy decoding (decode.hip)
+// the whole loop of model.py:204-219 in one persistent launch; every pointer is device memory
+struct DecodeArgs {
+    const float* E;                                 // (V, D) tied embedding
+    const float *W[8], *R[8], *bW[8], *bR[8];       // decoder GRU layers, G16 row order
+    const float *Kout, *bout;                       // out affine: kernel (D, D) as (in, out), bias (D)
+    float* state[2];                                // ping-pong (L, b, D); [0] holds state_in on entry
+    float* o;                                       // (b, D)
+    float* part_val; int32_t* part_idx;             // (G, b) partial argmax per workgroup, G = CU count
+    int32_t* ids_tm;                                // (steps + 1, b) time-major ids; row 0 = bos on entry
+    int32_t* out_ids;                               // (b, steps) result, eos beyond the kept tokens
+    int32_t* kept;                                  // [0] <- tokens kept per row
+    unsigned* bar;                                  // grid-barrier counter, zero on entry
+    int* err;                                       // error word (spin time-out)
+    int b, steps, D, V, L, eos, cache_e; float isd;
+};
+// returns hipErrorInvalidValue where the geometry does not fit (D / CUs > 2 units per workgroup, LDS), the caller
+// then falls back to one launch sequence per token; *grid_out = workgroups launched
+hipError_t decode_greedy(hipStream_t st, DecodeArgs a, int* grid_out);
+int decode_workgroups();                            // CU count of the current device (size of part_val / part_idx rows)
+
 // natural <-> G16 row permutation of a (3D, cols) matrix (cols = 1 for biases)
 hipError_t g16_permute(hipStream_t st, float* dst, const float* src, int D, int cols, bool to_g16);
 

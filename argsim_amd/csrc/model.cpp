@@ -939,15 +939,13 @@ int avae_decode_step(avae_handle h, const int32_t* lead, const float* state_in, 
     return check_gru_err(h);
 }
 
-int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, int32_t* out_ids, int32_t* n_steps)
+// one launch sequence per token with a host check every 16 tokens: the fallback where the persistent kernel's geometry
+// does not fit (decode.hip) and the reference form for tests (option "persistent" = 0)
+static int decode_greedy_stepwise(avae_handle h, const float* z, int32_t b, int32_t steps, int32_t* out_ids, int32_t* n_steps)
 {
-    if (!h) return 1;
-    AV_TRY(check_bound(h));
-    AV_CHECK(hipSetDevice(h->device));
     const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
     Ws w;
     AV_TRY(get_ws(h, w, b, 1, 1, false));
-    // state ping-pong + time-major id log live in the (otherwise idle) encoder buffers of the workspace
     const size_t sn = (size_t)L * b * D;
     float* state[2]; int32_t* ids_tm = nullptr;
     {
@@ -955,6 +953,7 @@ int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, 
         if (h->scratch_n < (int64_t)need) {
             AV_CHECK(hipStreamSynchronize(h->stream));
             if (h->scratch) AV_CHECK(hipFree(h->scratch));
+            h->scratch = nullptr; h->scratch_n = 0;
             AV_CHECK(hipMalloc(reinterpret_cast<void**>(&h->scratch), need));
             h->scratch_n = (int64_t)need;
         }
@@ -992,6 +991,61 @@ int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, 
     AV_CHECK(hipStreamSynchronize(h->stream));
     if (n_steps) *n_steps = kept;
     return check_gru_err(h);
+}
+
+int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, int32_t* out_ids, int32_t* n_steps)
+{
+    if (!h) return 1;
+    AV_TRY(check_bound(h));
+    if (b < 1 || steps < 1) return fail(h, "empty batch");
+    AV_CHECK(hipSetDevice(h->device));
+    // measured at D = 512, V = 8192, steps = 512 (scripts/decode_bench.py, gpurun_out/decode4.log): the persistent launch
+    // takes 42 / 74 / 145 us per token at b = 1 / 16 / 64, the launch-per-token loop 116-130 us at any b <= 128 (its
+    // GEMMs are far from full): one launch up to 32 rows, the per-token loop above
+    if (!h->persistent || b > 32) return decode_greedy_stepwise(h, z, b, steps, out_ids, n_steps);
+    // the whole loop in ONE persistent launch (decode.hip); state, partial maxima and the id log live in the scratch buffer
+    const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
+    const int G = decode_workgroups();
+    if (G < 1) return fail(h, "no HIP device");
+    const size_t sn = (size_t)L * b * D;
+    const size_t nf = 2 * sn + (size_t)b * D + (size_t)G * b;                                 // floats: state x2, o, part_val
+    const size_t ni = (size_t)G * b + (size_t)(steps + 1) * b + 16;                            // ints: part_idx, ids_tm, kept, barrier
+    const size_t need = (nf + ni) * 4;
+    if (h->scratch_n < (int64_t)need) {
+        AV_CHECK(hipStreamSynchronize(h->stream));
+        if (h->scratch) AV_CHECK(hipFree(h->scratch));
+        h->scratch = nullptr; h->scratch_n = 0;
+        AV_CHECK(hipMalloc(reinterpret_cast<void**>(&h->scratch), need));
+        h->scratch_n = (int64_t)need;
+    }
+    DecodeArgs a{};
+    a.E = h->P + h->oE;
+    for (int l = 0; l < L; ++l) { a.W[l] = h->P + h->dec[l].W; a.R[l] = h->P + h->dec[l].R; a.bW[l] = h->P + h->dec[l].bW; a.bR[l] = h->P + h->dec[l].bR; }
+    a.Kout = h->P + h->oKout; a.bout = h->P + h->oBout;
+    a.state[0] = h->scratch; a.state[1] = h->scratch + sn;
+    a.o = h->scratch + 2 * sn; a.part_val = a.o + (size_t)b * D;
+    int32_t* ip = reinterpret_cast<int32_t*>(h->scratch + nf);
+    a.part_idx = ip; a.ids_tm = ip + (size_t)G * b;
+    a.kept = a.ids_tm + (size_t)(steps + 1) * b; a.bar = reinterpret_cast<unsigned*>(a.kept + 8);
+    a.out_ids = out_ids; a.err = h->errw;
+    a.b = b; a.steps = steps; a.D = D; a.V = V; a.L = L; a.eos = h->cfg.eos; a.isd = 1.f / sqrtf((float)D);
+    AV_TRY(avae_decode_init(h, z, b, a.state[0]));
+    std::vector<int32_t> bos((size_t)b, h->cfg.bos);
+    AV_CHECK(hipMemcpyAsync(a.ids_tm, bos.data(), b * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    AV_CHECK(hipMemsetAsync(a.kept, 0, 16 * sizeof(int32_t), h->stream));
+    int grid = 0;
+    hipError_t e = decode_greedy(h->stream, a, &grid);
+    if (e == hipErrorInvalidValue) {                       // geometry outside the persistent kernel: same results, more launches
+        AV_CHECK(hipStreamSynchronize(h->stream));           // (bos.data() is still being read)
+        return decode_greedy_stepwise(h, z, b, steps, out_ids, n_steps);
+    }
+    if (e == hipErrorCooperativeLaunchTooLarge) return fail(h, "greedy decode kernel: one workgroup per CU does not fit this device");
+    AV_CHECK(e);
+    int kept = 0;
+    AV_CHECK(hipMemcpyAsync(&kept, a.kept, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AV_TRY(check_gru_err(h));                               // synchronises
+    if (n_steps) *n_steps = kept;
+    return 0;
 }
 
 }  // extern "C"

@@ -305,3 +305,26 @@ def test_row_block_pipelined_team_kernels_equal_stepwise(B, S):
     d = float((out[1][2] - out[0][2]).norm() / out[0][2].norm())
     assert d < 1e-5, d
     assert all(np.isfinite(out[1][3]))
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8(f) row 2
+@pytest.mark.parametrize("b", [1, 5, 32])
+def test_persistent_greedy_decode_equals_the_per_token_loop(b):
+    """model.py:204-219 in ONE persistent launch (decode.hip) against the launch-per-token loop of the same library at
+    the production dimensions (weights resident in LDS, grid barrier per phase): same ids, same early stop."""
+    from argsim_amd.model import VAE
+    m = VAE('infer', seed=2, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    rng = np.random.default_rng(b)
+    z = rng.standard_normal((b, 128)).astype(np.float32)
+    y1 = m.decode(z, steps=40)
+    m.set_option('persistent', 0)
+    y0 = m.decode(z, steps=40)
+    assert y1.shape == y0.shape and np.array_equal(y1, y0)
+    # early stop: a bias that makes eos win at once -> the loop ends before appending anything (model.py:217-218)
+    bias = m.get_tensor('decode/out/bias')
+    E = m.get_tensor('embed/embedding')
+    m.set_tensor('decode/out/bias', bias + 200.0 * E[1] / np.linalg.norm(E[1]))
+    m.set_option('persistent', 1)
+    assert m.decode(z, steps=40).shape == (b, 0)
+    m.set_option('persistent', 0)
+    assert m.decode(z, steps=40).shape == (b, 0)
