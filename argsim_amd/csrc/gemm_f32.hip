@@ -84,11 +84,72 @@ struct FastTile {
     }
 };
 
+// Epilogue of a (32 WM TM) x (32 WN TN) block tile.  C/D map of a 32x32 MFMA tile: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  MODE 0 store, 1 accumulate (+=), 2 float atomics (split-K).  A tile that lies
+// wholly inside the matrix takes the straight-line form (one address computation per 32x32 tile, no per-element
+// predicate or mode branch): the branchy generic form below costs ~40 instructions per element, which was ~15 % of
+// a K = 512 output tile.
+template <int MODE>
+__device__ __forceinline__ void put(float* c, float v)
+{
+    if (MODE == 2) atomicAdd(c, v);
+    else if (MODE == 1) *c += v;
+    else *c = v;
+}
+template <int TM, int TN, int WN, int MODE>
+__device__ __forceinline__ void epilogue_full(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int h, int l31, bool add_bias)
+{
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + 32 * (wn * TN + j) + l31;
+        const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float* c = g.C + (size_t)(m0 + 32 * (wm * TM + i) + 4 * h) * g.ldc + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                put<MODE>(c + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldc, g.alpha * acc[i][j][r] + bv);
+        }
+    }
+}
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int M, int m0, int n0, int BM, int BN,
+                                         int wm, int wn, int h, int l31, bool atomic, bool add_bias)
+{
+    // (split-K float atomics keep the generic form: 64 atomics per lane issued back to back ran 25 % SLOWER than the
+    //  same atomics spaced by the generic form's bookkeeping -- the memory-side atomic rate is the limit there)
+    if (!atomic && m0 + BM <= M && n0 + BN <= g.N) {            // uniform
+        if (g.accumulate) epilogue_full<TM, TN, WN, 1>(g, acc, m0, n0, wm, wn, h, l31, add_bias);
+        else epilogue_full<TM, TN, WN, 0>(g, acc, m0, n0, wm, wn, h, l31, add_bias);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int col = n0 + 32 * (wn * TN + j) + l31;
+        if (col >= g.N) continue;
+        float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + 32 * (wm * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
 // WM x WN waves (WM*WN = 4), each TM x TN MFMA tiles of 32x32: block tile BM = 32 WM TM, BN = 32 WN TN.
 // <2,2,2,2> = 128x128 is the workhorse; <1,4,1,1> = 32x128 serves thin row panels (M <= 512 and the
 // remainder rows of a tile count just above a multiple of 256) deterministically, without split-K.
+// (register budget pinned to the residency the launch shaping assumes: 3 workgroups per CU, 2 for the double-buffered form)
 template <bool A_MC, bool B_NC, int WM, int WN, int TM, int TN, bool FAST = false, bool DB = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
+__global__ __launch_bounds__(256, DB ? 2 : 3) void gemm_f32_kernel(GemmArgs g)
 {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int kStage = (BM + BN) * LDK;
@@ -211,27 +272,112 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         __syncthreads();
     }
 
-    // epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool atomic = g.split_k > 1;
     const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int col = n0 + 32 * (wn * TN + j) + l31;
-        if (col >= g.N) continue;
-        float bv = add_bias ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = m0 + 32 * (wm * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                float v = g.alpha * acc[i][j][r] + bv;
-                float* c = g.C + (size_t)row * g.ldc + col;
-                if (atomic) atomicAdd(c, v);
-                else if (g.accumulate) *c += v;
-                else *c = v;
-            }
+    epilogue<TM, TN, WN>(g, acc, M, m0, n0, BM, BN, wm, wn, h, l31, atomic, add_bias);
+}
+
+// Persistent form of the 128x128 kernel for GEMMs of more than one round of tiles (no split-K): 768 workgroups
+// (3 per CU) walk the tiles of their XCD's run round-robin, and the first K tile of a workgroup's NEXT output tile is
+// put in flight before the epilogue of the current one, so the global-load latency of a tile's prologue -- which all
+// workgroups of a round otherwise pay together -- hides behind the last MFMAs and the C stores.  Measured on the
+// step's short-K shapes (K = 512: 16 K tiles per output tile) the per-tile overhead was ~14 % of the tile.
+template <bool A_MC, bool B_NC, bool FAST>
+__global__ __launch_bounds__(256, 3) void gemm_f32_persist_kernel(GemmArgs g)
+{
+    static_assert(FAST, "buffer-load staging only (register budget of three workgroups per CU)");
+    constexpr int TM = 2, TN = 2, WN = 2, BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int M = g.M;
+    const int K = g.K;
+    if (g.dyn_kind == 1) M = min(M, *g.dyn);
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int nblk = ((M + BM - 1) / BM) * tiles_n;
+    // XCD-aware order (see gemm_f32_kernel): workgroups g, g + 8, ... share an XCD and walk its contiguous run of tiles
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, run_n = q + (xcd < r ? 1 : 0);
+    int local = blockIdx.x >> 3;
+    if (local >= run_n) return;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    FastTile<A_MC, BM> fa; FastTile<B_NC, BN> fb;
+    auto first_tile = [&](int bid) __attribute__((always_inline)) {          // loads K tile 0 of output tile `bid`
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        if (FAST) {
+            fa.init(g.A, g.lda, tm * BM, M, 0, K, tid); fb.init(g.B, g.ldb, tn * BN, g.N, 0, K, tid);
+            fa.load(ra, 0); fb.load(rb, 0);
+        } else {
+            load_tile<A_MC, BM>(ra, g.A, g.lda, tm * BM, M, 0, K, tid);
+            load_tile<B_NC, BN>(rb, g.B, g.ldb, tn * BN, g.N, 0, K, tid);
         }
+    };
+    first_tile(run0 + local);
+    for (; local < run_n; local += per_xcd) {
+        const int bid = run0 + local;
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+        const bool more = local + per_xcd < run_n;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            store_tile<A_MC, BM>(As, ra, tid);
+            store_tile<B_NC, BN>(Bs, rb, tid);
+            __syncthreads();
+            if (k0 + BK < K) {
+                if (FAST) { const int it = k0 / BK + 1; fa.load(ra, it); fb.load(rb, it); }
+                else {
+                    load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, k0 + BK, K, tid);
+                    load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, K, tid);
+                }
+            } else if (more) {
+                first_tile(bid + per_xcd);                    // the next output tile's first K tile, behind these MFMAs
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float a[TM][4], b[TN][4];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    if (A_MC) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[t][e] = As[(8 * qq + 4 * h + e) * BM + 32 * (wm * TM + t) + l31];
+                    } else {
+                        float4 v = *reinterpret_cast<const float4*>(As + (32 * (wm * TM + t) + l31) * LDK + 8 * qq + 4 * h);
+                        a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    if (B_NC) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b[t][e] = Bs[(8 * qq + 4 * h + e) * BN + 32 * (wn * TN + t) + l31];
+                    } else {
+                        float4 v = *reinterpret_cast<const float4*>(Bs + (32 * (wn * TN + t) + l31) * LDK + 8 * qq + 4 * h);
+                        b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        epilogue<TM, TN, WN>(g, acc, M, m0, n0, BM, BN, wm, wn, h, l31, false, g.bias != nullptr);
     }
 }
 
@@ -252,6 +398,22 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
     // (768 slots).  Double-buffered: one barrier per K tile, 2 workgroups per CU (512 slots); measured 3-8 % slower at
     // equal balance, but a tile count in (768, 1024] runs as ONE balanced round instead of a full round plus a round
     // that leaves most slots empty (1024 tiles: 112 -> 130 TFLOP/s, gpurun_out/gb_db.log).
+    // more than one round of tiles, no split-K: the persistent form (cross-tile prefetch)
+    static const char* ps_env = getenv("AVAE_F32_PERSIST");
+    if constexpr (WM == 2 && WN == 2) {
+        // (only with the buffer-load staging: the predicated staging needs more registers than three workgroups per
+        //  CU leave, and its longer prologue no longer matters once the prologue is prefetched)
+        const bool aligned = (a_mc ? (g.M % BM == 0) : (g.K % BK == 0)) && (b_nc ? (g.N % BN == 0) : (g.K % BK == 0));
+        const bool persist = (ps_env ? atoi(ps_env) != 0 : true) && allow_fast && aligned && g.split_k <= 1 && g.dyn_kind != 2 && tiles > 1024;
+        if (persist) {
+            dim3 pg(768);
+            if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_persist_kernel<false, false, true>), pg, dim3(256), 0, st, g);
+            else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32_persist_kernel<false, true, true>), pg, dim3(256), 0, st, g);
+            else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32_persist_kernel<true, true, true>), pg, dim3(256), 0, st, g);
+            else                     hipLaunchKernelGGL((gemm_f32_persist_kernel<true, false, true>), pg, dim3(256), 0, st, g);
+            return;
+        }
+    }
     static const char* db_env = getenv("AVAE_F32_DB");
     if constexpr (WM == 2 && WN == 2) {
         const bool use_db = db_env ? atoi(db_env) != 0 : (g.split_k <= 1 && g.dyn_kind != 1 && tiles > 768 && tiles <= 1024);
