@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void gemm_f32_kernel(GemmArgs g)
     const int h = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
 
+    if (blockIdx.y) { g.A = g.A2; g.B = g.B2; g.C = g.C2; g.bias = g.bias2; }      // second problem of a pair (kernels.h)
     int M = g.M, K = g.K;
     if (g.dyn_kind == 1) M = min(M, *g.dyn);
     if (g.dyn_kind == 2) K = min(K, *g.dyn);
@@ -386,7 +387,7 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
 {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
+    dim3 grid(tiles, g.A2 ? 2 : 1, g.split_k > 1 ? g.split_k : 1);
     // fast staging: k-contiguous operand: K a multiple of BK, known on the host; [k][x] operand: x extent a multiple of the tile
     static const bool allow_fast = !getenv("AVAE_F32_NOFAST");
     // (measured: +4..9 % where an operand is stored [k][x] or the K extent is long; the NT shapes with K <= 1024
@@ -404,7 +405,7 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
         // (only with the buffer-load staging: the predicated staging needs more registers than three workgroups per
         //  CU leave, and its longer prologue no longer matters once the prologue is prefetched)
         const bool aligned = (a_mc ? (g.M % BM == 0) : (g.K % BK == 0)) && (b_nc ? (g.N % BN == 0) : (g.K % BK == 0));
-        const bool persist = (ps_env ? atoi(ps_env) != 0 : true) && allow_fast && aligned && g.split_k <= 1 && g.dyn_kind != 2 && tiles > 1024;
+        const bool persist = (ps_env ? atoi(ps_env) != 0 : true) && allow_fast && aligned && !g.A2 && g.split_k <= 1 && g.dyn_kind != 2 && tiles > 1024;
         if (persist) {
             dim3 pg(768);
             if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_persist_kernel<false, false, true>), pg, dim3(256), 0, st, g);
@@ -416,7 +417,7 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
     }
     static const char* db_env = getenv("AVAE_F32_DB");
     if constexpr (WM == 2 && WN == 2) {
-        const bool use_db = db_env ? atoi(db_env) != 0 : (g.split_k <= 1 && g.dyn_kind != 1 && tiles > 768 && tiles <= 1024);
+        const bool use_db = db_env ? atoi(db_env) != 0 && !g.A2 : (!g.A2 && g.split_k <= 1 && g.dyn_kind != 1 && tiles > 768 && tiles <= 1024);
         if (use_db) {
             if (fast) {
                 if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, g);
@@ -449,7 +450,7 @@ hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
 {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if ((g.lda | g.ldb) & 3) return hipErrorInvalidValue;
-    if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) return hipErrorInvalidValue;
+    if (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.A2 | (uintptr_t)g.B2) & 15) return hipErrorInvalidValue;
     // contiguous extents must be multiples of 4 (float4 staging)
     if (!a_mc && (g.K & 3)) return hipErrorInvalidValue;
     if (a_mc && (g.M & 3)) return hipErrorInvalidValue;

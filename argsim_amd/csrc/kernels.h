@@ -24,6 +24,10 @@ struct GemmArgs {
     int split_k;
     const int* dyn; int dyn_kind;
     int thin;            // 1: 32x128 block tiles (thin row panels) instead of 128x128
+    // optional second problem of identical shape, layout and scalars, run by the same launch (grid.y = 2): two
+    // weight-gradient GEMMs over the same rows then share ONE round of workgroups at half the K split (half the
+    // float-atomic traffic each), two small affines share one launch.  Exact-fp32 kernel only.
+    const float* A2; const float* B2; float* C2; const float* bias2;
 };
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 // same contract on the bf16 matrix cores: every fp32 operand element is split into three bf16 in registers and

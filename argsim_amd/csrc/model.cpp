@@ -209,12 +209,20 @@ int grow_bf16(avae_ctx* h, unsigned short** buf, size_t* cap, size_t need)
     return 0;
 }
 
+// second problem of a pair (same shape, layout, scalars): see GemmArgs in kernels.h
+struct Pair { const float* A; const float* B; float* C; const float* bias; };
+
 int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
              int M, int N, int K, float alpha, const float* bias, int accumulate, int split_k, const int* dyn, int dyn_kind,
-             int thin = 0)
+             int thin = 0, const Pair* pair = nullptr)
 {
-    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin};
-    Timed t(h, 0, 2.0 * M * N * K);
+    if (pair && h->cfg.compute_dtype != 0) {     // the other GEMM kernels take one problem per launch
+        AV_TRY(gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, split_k, dyn, dyn_kind, thin));
+        return gemm_raw(h, a_mc, b_nc, pair->A, lda, pair->B, ldb, pair->C, ldc, M, N, K, alpha, pair->bias, accumulate, split_k, dyn, dyn_kind, thin);
+    }
+    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin,
+               pair ? pair->A : nullptr, pair ? pair->B : nullptr, pair ? pair->C : nullptr, pair ? pair->bias : nullptr};
+    Timed t(h, 0, 2.0 * M * N * K * (pair ? 2 : 1));
     if (h->cfg.compute_dtype == 1) {
         // bf16 operands: convert (transposing [k][x] operands) into k-contiguous panels, then one NT kernel
         const int Kp = (K + 7) & ~7;
@@ -293,10 +301,11 @@ int grad_split(int M, int N, int K)
 }
 // dW (M x N) += A^T B over K rows; A [k][m] lda, B [k][n] ldb.  grads are zero-filled beforehand.
 int gemm_tn_grad(avae_ctx* h, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                 float alpha = 1.f, const int* dynk = nullptr)
+                 float alpha = 1.f, const int* dynk = nullptr, const Pair* pair = nullptr)
 {
-    int s = grad_split(M, N, K);
-    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0);
+    // a pair shares the ~768 workgroups: half the K split, half the float-atomic traffic per problem
+    int s = (pair && h->cfg.compute_dtype == 0) ? grad_split(2 * M, N, K) : grad_split(M, N, K);
+    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, 0, pair);
 }
 
 void gru_geometry(int D, int njobs, int B, int* G, int* rpg)
@@ -357,8 +366,10 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 int run_latent(avae_ctx* h, Ws& w, int B, bool train, uint64_t seed, const float* eps)
 {
     const int D = h->cfg.dim_emb, R = h->cfg.dim_rep;
-    AV_TRY(gemm(h, false, true, w.hpick, 2 * D, h->P + h->oWmu, R, w.mu, R, B, R, 2 * D, 1.f, h->P + h->oBmu));
-    AV_TRY(gemm(h, false, true, w.hpick, 2 * D, h->P + h->oWlv, R, w.lv, R, B, R, 2 * D, 1.f, h->P + h->oBlv));
+    {   // mu and lv (model.py:149-150): two affines of the same input, one launch
+        const Pair lv{w.hpick, h->P + h->oWlv, w.lv, h->P + h->oBlv};
+        AV_TRY(gemm_raw(h, false, true, w.hpick, 2 * D, h->P + h->oWmu, R, w.mu, R, B, R, 2 * D, 1.f, h->P + h->oBmu, 0, 1, nullptr, 0, B <= 512 ? 1 : 0, &lv));
+    }
     AV_CHECK(latent_fwd(h->stream, w.mu, w.lv, eps, w.eps, w.z, w.kld, B * R, train ? 1 : 0, seed, h->cfg.free_bits, h->acc + 1));
     return 0;
 }
@@ -481,8 +492,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
-        AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt));
-        AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
+        {   // dW = dgi^T x and dR = dgh^T h_prev: same shape over the same rows, one launch
+            const Pair dR{w.dgh_d, w.d_hp[i], G + p.R, nullptr};
+            AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr, &dR));
+        }
         float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
         AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
@@ -497,9 +510,11 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_TRY(gemm(h, false, false, w.dh0sum, D, P + h->oWex, D, w.dz, R, B, R, D));
     float bg = b_global > 0.f ? b_global : (float)B;
     AV_CHECK(latent_bwd(st, w.dz, w.mu, w.lv, w.eps, w.dmu, w.dlv, B, R, sc.anneal * h->cfg.kl_beta / (bg * R), h->cfg.free_bits));
-    AV_TRY(gemm_tn_grad(h, w.hpick, 2 * D, w.dmu, R, G + h->oWmu, R, 2 * D, R, B));
+    {
+        const Pair dlv{w.hpick, w.dlv, G + h->oWlv, nullptr};
+        AV_TRY(gemm_tn_grad(h, w.hpick, 2 * D, w.dmu, R, G + h->oWmu, R, 2 * D, R, B, 1.f, nullptr, &dlv));
+    }
     AV_CHECK(colsum(st, w.dmu, B, R, R, G + h->oBmu, nullptr));
-    AV_TRY(gemm_tn_grad(h, w.hpick, 2 * D, w.dlv, R, G + h->oWlv, R, 2 * D, R, B));
     AV_CHECK(colsum(st, w.dlv, B, R, R, G + h->oBlv, nullptr));
     AV_TRY(gemm(h, false, false, w.dmu, R, P + h->oWmu, R, w.dhpick, 2 * D, B, 2 * D, R));
     AV_TRY(gemm(h, false, false, w.dlv, R, P + h->oWlv, R, w.dhpick, 2 * D, B, 2 * D, R, 1.f, nullptr, 1));
@@ -528,8 +543,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         hook_flush(h);
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
-        for (int d = 0; d < 2; ++d)
-            AV_TRY(gemm_tn_grad(h, w.dgh_e + d * 3 * D, 6 * D, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs));
+        {   // dR of the two directions: same shape, one launch
+            const Pair bwd{w.dgh_e + 3 * D, w.e_hp[1][i], G + p.R + (int64_t)3 * D * D, nullptr};
+            AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, nullptr, &bwd));
+        }
         float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
         AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
