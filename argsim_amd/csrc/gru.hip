@@ -625,8 +625,6 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
 // pipe.  Teams synchronise through two monotonic LDS counters per team (LDS atomics + LDS polling; never
 // s_barrier, which would put the four chains in lock step).  Exchange between workgroups: the same in-band
 // sentinel protocol as above.
-constexpr int kTeams = 4;
-struct TeamSync { unsigned arrive[kTeams]; };
 
 __device__ __forceinline__ void team_barrier(unsigned* word, unsigned target)
 {
@@ -641,14 +639,14 @@ __device__ __forceinline__ void team_barrier(unsigned* word, unsigned target)
 // plus the 64-row blocks slot, slot + cpj, ... of that job (cpj = chain groups per job); the 32 workgroups of a chain
 // group exchange with each other and share blockIdx % C (one XCD under round-robin dispatch when C = 8; speed only).
 struct TeamMap { int cid, ht, jb, slot, cpj, nrb; };
-__device__ __forceinline__ TeamMap team_map(const GruArgs& a)
+__device__ __forceinline__ TeamMap team_map(const GruArgs& a, int rows_per_block)
 {
     TeamMap m;
     const int C = gridDim.x / 32;
     m.cid = blockIdx.x % C; m.ht = blockIdx.x / C;
     m.cpj = C / a.njobs;
     m.jb = m.cid / m.cpj; m.slot = m.cid % m.cpj;
-    m.nrb = (a.B / 64) / m.cpj;
+    m.nrb = (a.B / rows_per_block) / m.cpj;
     return m;
 }
 
@@ -657,34 +655,38 @@ __device__ __forceinline__ TeamMap team_map(const GruArgs& a)
 // item depends on this one's own stores): polled and loaded at the top of the item.  Two instantiations so that each
 // has ONE load site inside the loop -- with two, the register allocator parks the prefetched fragment in other
 // registers and copies it at the loop edge, which waits for the loads exactly where they were meant to overlap.
-template <bool DIAG, bool PIPE>
+// T teams of KS = 16 / T waves: T = 4 (64 rows per workgroup, K split over 4 waves) where a job fills the chip with 64-row
+// blocks, T = 2 (32 rows, K split over 8 waves: half the MFMAs and half the operand bytes per wave and step on the
+// latency chain) where it does not, e.g. one decoder layer at B = 256.
+template <bool DIAG, bool PIPE, int T>
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
     const int ab = DIAG ? a.ablate : 0;                     // timing experiments / stamps: diagnostic instantiation only
-    constexpr int D = 512, HT = 32, WK = 128;
+    constexpr int D = 512, HT = 32, KS = 16 / T, WK = D / KS, NQ = WK / 16, RB = 16 * T, TT = 64 * KS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wl = lds;                                        // [wk 4][gate 3][q 8][lane 64][4]   96 KB
-    float* part = Wl + 4 * 3 * 8 * 256;                     // [team 4][wk 4][gate 3][256]        48 KB
-    float* hps = part + kTeams * 4 * 3 * 256;               // [team 4][16][16]                    4 KB
-    unsigned* sync = reinterpret_cast<unsigned*>(hps + kTeams * 256);      // [team 4]
+    float* Wl = lds;                                        // [wk KS][gate 3][q NQ][lane 64][4]    96 KB
+    float* part = Wl + 96 * 256;                            // [team T][wk KS][gate 3][256]         48 KB
+    float* hps = part + 48 * 256;                           // [team T][16][16]
+    unsigned* sync = reinterpret_cast<unsigned*>(hps + T * 256);      // [team T] barrier counters, [team T] exchange-ready epochs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int team = wave >> 2, wk = wave & 3;
+    const int team = wave / KS, wk = wave % KS;
     const int n = lane & 15, kh = lane >> 4;
-    const TeamMap tm = team_map(a);
+    const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
     const GruJob& J = a.job[tm.jb];
     const int B = a.B;
 
     // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
     for (int blk = wave; blk < 96; blk += 16) {
-        const int wq = blk / 24, gate = (blk / 8) % 3, q = blk & 7;
+        const int wq = blk / (3 * NQ), gate = (blk / NQ) % 3, q = blk % NQ;
         const float4 v = *reinterpret_cast<const float4*>(J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 16 * q + 4 * kh);
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = v;
     }
-    if (tid < 2 * kTeams) sync[tid] = 0u;                   // [0..3] team barrier counters, [4..7] exchange-ready epochs
-    const int tt = tid & 255;                               // thread inside the team
-    const int gn = tt & 15, gr = tt >> 4;
+    if (tid < 2 * T) sync[tid] = 0u;
+    const int tt = tid % TT;                                // thread inside the team; its first 256 threads do the gate math
+    const bool gate_thread = tt < 256;
+    const int gn = tt & 15, gr = (tt >> 4) & 15;
     const int j = ht * 16 + gn;
     float bR[3];
 #pragma unroll
@@ -692,10 +694,10 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int own_wk = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
-    float* tpart = part + team * (4 * 3 * 256);
+    float* tpart = part + team * (KS * 3 * 256);
     float* thps = hps + team * 256;
     unsigned* tsync = sync + team;
-    unsigned* ready = sync + kTeams + team;
+    unsigned* ready = sync + T + team;
     unsigned epoch = 0;
     // de-phase the four chains: identical chains started together stay in lock step and collide on the matrix
     // pipe; an initial offset of a fraction of a step per team persists (equal periods)
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     // behind the MFMAs of the others (software pipelining over the row blocks; time is then linear in rows at the
     // matrix-pipe rate instead of at the chain latency).
     unsigned it = 0;                                          // items done so far (monotonic; LDS epochs derive from it)
-    u32x4 ra[8];
+    u32x4 ra[NQ];
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first 16-byte piece
         const int row = row0 + n;
         const unsigned o = (p == 0) ? (unsigned)((size_t)row * D * 4)
@@ -726,32 +728,33 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     };
     auto next_frag = [&](int p2, int r2, int len2) __attribute__((always_inline)) {   // PIPE: issue (or zero) the fragment of item (p2, r2)
         if (p2 > 0 || J.h0 != nullptr) {
-            const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
-            frag_issue<8>(ra, (p2 == 0) ? rs_h0 : rs_hs, a_offset(p2, row2, len2));
+            const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
+            frag_issue<NQ>(ra, (p2 == 0) ? rs_h0 : rs_hs, a_offset(p2, row2, len2));
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
+            for (int q = 0; q < NQ; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
     };
     // sequence lengths of the rows this lane touches in the current item (A rows: n, gate rows: tid's row)
-    int len_a = J.reverse ? a.lens[tm.slot * 64 + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * 64 + team * 16 + (tid & 255) / 16] : 0;
+    int len_a = J.reverse ? a.lens[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * RB + team * 16 + gr] : 0;
     if constexpr (PIPE) next_frag(a.p_begin, 0, len_a);
     for (int p = a.p_begin; p < a.p_end; ++p) {
       for (int r = 0; r < tm.nrb; ++r, ++it) {
         TSTAMP(5);
-        const int row0 = (tm.slot + r * tm.cpj) * 64 + team * 16;     // this team's 16 rows of row block r
+        const int row0 = (tm.slot + r * tm.cpj) * RB + team * 16;     // this team's 16 rows of row block r
         const bool poll = p > a.p_begin && !(ab & 16);            // ablate 16: timing experiment, wrong results
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
         const float* gp = J.gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
-        const float gi0 = gp[0], gi1 = gp[1], gi2 = gp[2];
+        float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f;
+        if (gate_thread) { gi0 = gp[0]; gi1 = gp[1]; gi2 = gp[2]; }
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
         const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p + 1;
         int len2 = len_a, len2g = len_g;
         if constexpr (PIPE) {
             if (J.reverse && p2 < a.p_end) {
-                const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+                const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
                 len2 = a.lens[row2 + n]; len2g = a.lens[row2 + gr];
             }
         }
@@ -778,12 +781,12 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                         while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                frag_issue<8>(ra, rs, aoff);
+                frag_issue<NQ>(ra, rs, aoff);
             }
-            if (poll) frag_ensure<8>(ra, rs, aoff, a.err);
+            if (poll) frag_ensure<NQ>(ra, rs, aoff, a.err);
         } else if constexpr (!PIPE) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
+            for (int q = 0; q < NQ; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
         TSTAMP(0);
         // (3) MFMAs, B fragments from LDS
@@ -791,11 +794,11 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             f32x4 b[3];
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
-                b[gate] = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 3 + gate) * 8 + q) * 256 + lane * 4);
+                b[gate] = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 3 + gate) * NQ + q) * 256 + lane * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)            // gates interleaved: consecutive MFMAs hit different accumulators
 #pragma unroll
@@ -805,14 +808,14 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         TSTAMP(1);
         // every wave of the team has finished READING the previous item's partial sums (second team barrier
         // of that item, taken here so that it costs nothing), then publish this item's
-        if (it > 0) { epoch += 4; team_barrier(tsync, epoch); }
+        if (it > 0) { epoch += KS; team_barrier(tsync, epoch); }
         TSTAMP(6);
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
             *reinterpret_cast<f32x4*>(tpart + (wk * 3 + gate) * 256 + lane * 4) = acc[gate];
         if (wk == own_wk) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < NQ; ++q)
                 if (q == own_q) *reinterpret_cast<u32x4*>(thps + n * 16 + 4 * kh) = ra[q];
         }
         // (3b) PIPE: the NEXT item is another chain, whose operand every producer stored an item ago.  Its loads go in
@@ -827,16 +830,19 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
         TSTAMP(7);
-        epoch += 4; team_barrier(tsync, epoch);
+        epoch += KS; team_barrier(tsync, epoch);
         TSTAMP(2);
         // (4) gate math: the team's 256 threads, one element each; exchanged store first
-        {
+        if (gate_thread) {
             const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
             float gh[3];
 #pragma unroll
-            for (int gate = 0; gate < 3; ++gate)
-                gh[gate] = bR[gate] + ((tpart[(0 * 3 + gate) * 256 + pidx] + tpart[(1 * 3 + gate) * 256 + pidx]) +
-                                       (tpart[(2 * 3 + gate) * 256 + pidx] + tpart[(3 * 3 + gate) * 256 + pidx]));
+            for (int gate = 0; gate < 3; ++gate) {
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};          // K-split partial sums, the order of the 4-wave form: ((0+1)+(2+3))
+#pragma unroll
+                for (int k = 0; k < KS; ++k) s4[k & 3] += tpart[(k * 3 + gate) * 256 + pidx];
+                gh[gate] = bR[gate] + ((s4[0] + s4[1]) + (s4[2] + s4[3]));
+            }
             const float hprev = thps[gr * 16 + gn];
             const float r_ = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r_ * gh[2]);
             const float hnew = (1.f - u) * nn + u * hprev;
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         TSTAMP(3);
       }
     }
-    if (stamp && (tid & 255) == 0 && a.stamps) {
+    if (stamp && tt == 0 && a.stamps) {
         for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, ph[i]);
         atomicAdd(a.stamps + 8, (unsigned long long)(a.p_end - a.p_begin));
         atomicAdd(a.stamps + 10, 1ULL);
@@ -1132,36 +1138,37 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 // probe of the register-form D = 512 path above, with a ring of NB 24-register pieces (128-register budget at 4 waves
 // per SIMD) whose first NB pieces are in flight before the MFMAs start.  A job with dh0 (decoder layers) gets the
 // tail item p = -1: dh0 = carry + dgh_0 R.  Teams synchronise through monotonic LDS counters, never s_barrier.
-template <int NB, bool PIPE>          // PIPE: several row blocks per workgroup (see the forward)
+template <int NB, bool PIPE, int T>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves (see the forward)
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
-    constexpr int D = 512, HT = 32, NH = 4, PQ = 6;
+    constexpr int D = 512, HT = 32, PQ = 6, KS = 16 / T, WKB = 3 * D / KS, NH = WKB / 96, KB4 = 96 / KS, RB = 16 * T, TT = 64 * KS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wl = lds;                                        // [wk 4][ks4 24][lane 64][4]      96 KB
-    float* part = Wl + 4 * 24 * 256;                        // [team 4][wk 4][256]             16 KB
-    float* red = part + kTeams * 4 * 256;                   // [4][16] bias-gradient sums
+    float* Wl = lds;                                        // [wk KS][ks4 KB4][lane 64][4]    96 KB
+    float* part = Wl + 96 * 256;                            // [team T][wk KS][256]            16 KB
+    float* red = part + 16 * 256;                           // [4][16] bias-gradient sums
     unsigned* sync = reinterpret_cast<unsigned*>(red + 64); // [team 4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int team = wave >> 2, wk = wave & 3;
+    const int team = wave / KS, wk = wave % KS;
     const int n = lane & 15, kh = lane >> 4;
-    const TeamMap tm = team_map(a);
+    const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
     const GruJob& J = a.job[tm.jb];
     const int B = a.B, S = a.S;
 
     // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
     for (int blk = wave; blk < 96; blk += 16) {
-        const int wq = blk / 24, ks4 = blk % 24;
-        const float* rp = J.R + (size_t)(wq * 384 + 16 * ks4 + 4 * kh) * D + ht * 16 + n;
+        const int wq = blk / KB4, ks4 = blk % KB4;
+        const float* rp = J.R + (size_t)(wq * WKB + 16 * ks4 + 4 * kh) * D + ht * 16 + n;
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[D], rp[2 * D], rp[3 * D]);
     }
-    if (tid < kTeams) sync[tid] = 0u;
+    if (tid < T) sync[tid] = 0u;
     if (tid < 64) red[tid] = 0.f;
-    const int tt = tid & 255, gn = tt & 15, gr = tt >> 4;
+    const int tt = tid % TT, gn = tt & 15, gr = (tt >> 4) & 15;
+    const bool gate_thread = tt < 256;                        // the team's first 256 threads own one (row, unit) each
     const int j = ht * 16 + gn;
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
-    float* tpart = part + team * (4 * 256);
+    float* tpart = part + team * (KS * 256);
     unsigned* tsync = sync + team;
     unsigned epoch = 0;
     {
@@ -1180,7 +1187,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
-        return (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * 384) * 4) + 16 * kh;
+        return (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * WKB) * 4) + 16 * kh;
     };
     auto issue_piece = [&](int piece, u32x4 (&dst)[PQ], unsigned vo) __attribute__((always_inline)) {
         if (piece == 0) asm_issue6<0>(dst, vo, srd);
@@ -1200,7 +1207,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     // over-wait
     auto next_head = [&](int p2, int r2, int len2) __attribute__((always_inline)) {
         if (p2 + 1 < S) {
-            const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+            const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
             const unsigned vo2 = a_offset(p2, row2, len2);
 #pragma unroll
             for (int s0 = 0; s0 < NB && s0 < NH; ++s0)
@@ -1208,11 +1215,11 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 for (int q = 0; q < PQ; ++q) hv[s0][q] = load16_sc1(rs_dgh, vo2 + 384u * s0 + 64u * q);
         }
     };
-    int len_a = J.reverse ? a.lens[tm.slot * 64 + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * 64 + team * 16 + gr] : 0;
+    int len_a = J.reverse ? a.lens[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * RB + team * 16 + gr] : 0;
     if constexpr (PIPE) next_head(a.p_end - 1, 0, len_a);
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
       for (int r = 0; r < tm.nrb; ++r, ++it) {
-        const int row0 = (tm.slot + r * tm.cpj) * 64 + team * 16;
+        const int row0 = (tm.slot + r * tm.cpj) * RB + team * 16;
         const int grow = row0 + gr;
         const bool have_next = p + 1 < S;
         const bool poll = done > 0;
@@ -1221,14 +1228,14 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         int len2 = len_a, len2g = len_g;
         if constexpr (PIPE) {
             if (J.reverse && p2 >= p_last) {
-                const int row2 = (tm.slot + r2 * tm.cpj) * 64 + team * 16;
+                const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
                 len2 = a.lens[row2 + n]; len2g = a.lens[row2 + gr];
             }
         }
         // (1) exchange-independent loads of the gate phase
         const size_t rix = (size_t)pos_map(p < 0 ? 0 : p, len_g, J.reverse) * B + grow;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
-        if (p >= 0) {
+        if (p >= 0 && gate_thread) {
             sv = *reinterpret_cast<const float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4);
             s_hp = J.hp[rix * D + j];
             s_do = J.dh_out ? J.dh_out[rix * a.ldh + j] : 0.f;
@@ -1238,7 +1245,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         //  behind them would wait for them)
         float* carryp = J.carry + (size_t)grow * D + j;
         float s_carry = 0.f;
-        if constexpr (PIPE) { if (have_next) s_carry = *carryp; }
+        if constexpr (PIPE) { if (have_next && gate_thread) s_carry = *carryp; }
         // (2)+(3) A operand = dgh_{p+1} of the team's 16 rows, this wave's K quarter, in four 96-float pieces
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         if (have_next) {
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                     asm volatile("" : "+v"(mx));
 #pragma unroll
                     for (int q = 0; q < PQ; ++q) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 24 + st * 6 + q) * 64 + lane) * 4);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * KB4 + st * 6 + q) * 64 + lane) * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][q][e]), b[e], acc[e & 1], 0, 0, 0);
@@ -1298,13 +1305,16 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
         // every wave of the team has finished READING the previous item's partial sums, then publish this item's
-        if (it > 0) { epoch += 4; team_barrier(tsync, epoch); }
+        if (it > 0) { epoch += KS; team_barrier(tsync, epoch); }
         *reinterpret_cast<f32x4*>(tpart + wk * 256 + lane * 4) = sum;
-        epoch += 4; team_barrier(tsync, epoch);
+        epoch += KS; team_barrier(tsync, epoch);
         // (4) gate derivatives: the team's 256 threads, one (row, unit) each; exchanged stores first
-        {
+        if (gate_thread) {
             const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
-            float carried = (tpart[pidx] + tpart[256 + pidx]) + (tpart[512 + pidx] + tpart[768 + pidx]);
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) s4[k & 3] += tpart[k * 256 + pidx];
+            float carried = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             if constexpr (PIPE) carried += s_carry;
             else if (have_next) carried += *carryp;
             if (p < 0) { J.dh0[(size_t)grow * D + j] = carried; len_a = len2; len_g = len2g; continue; }
@@ -1444,16 +1454,23 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd)
 }
 
 // geometry of the LDS-weight team kernels: C <= 8 chain groups x 32 hidden tiles = at most one 1024-thread workgroup
-// per CU; a chain group = one job and every (C / njobs)-th 64-row block of it.  Returns false where they do not apply.
-static bool team_geometry(const GruArgs& a, int* C)
+// per CU; a chain group = one job and every (C / njobs)-th block of 16 T rows of it.  T = 4 teams (64-row blocks) where
+// that fills the chip, else T = 2 (32-row blocks, K split over 8 waves).  Returns false where neither applies.
+static bool team_geometry(const GruArgs& a, int* T, int* C)
 {
-    if (a.D != 512 || a.B % 64 || a.njobs > 2) return false;
-    const int nrbj = a.B / 64, np = a.njobs * nrbj;
-    if (np <= 8) { *C = np; return true; }
-    const int cpj = 8 / a.njobs;
-    if (nrbj % cpj) return false;
-    *C = 8;
-    return true;
+    if (a.D != 512 || a.njobs > 2) return false;
+    for (int t = 4; t >= 2; t >>= 1) {
+        const int rb = 16 * t;
+        if (a.B % rb) continue;
+        const int nrbj = a.B / rb, np = a.njobs * nrbj;
+        if (np < 8) continue;                       // would leave CUs idle: try smaller blocks
+        if (np == 8) { *T = t; *C = 8; return true; }
+        const int cpj = 8 / a.njobs;
+        if (nrbj % cpj) continue;
+        *T = t; *C = 8;
+        return true;
+    }
+    return false;
 }
 
 template <class K>
@@ -1480,19 +1497,21 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
         e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
-        // D = 512, B a multiple of 64: four independent 16-row teams per CU, weights in LDS, the row blocks of a
-        // workgroup interleaved item by item.  A single job with fewer than 8 row blocks (a decoder layer at B = 256)
-        // would leave half the CUs idle: the register form below spreads it over all of them.
-        int C = 0;
-        if (team_geometry(a, &C) && (a.njobs == 2 || C == 8) && a.item_pipeline == 2) {
-            const int lds_bytes = (4 * 3 * 8 * 256 + kTeams * 4 * 3 * 256 + kTeams * 256) * 4 + 128;
-            const bool pipe = a.njobs * (a.B / 64) > C;      // several row blocks per workgroup
+        // D = 512: independent 16-row teams sharing one LDS-resident weight slice per CU, the row blocks of a workgroup
+        // interleaved item by item (team_geometry picks 4 teams x 4 waves or 2 teams x 8 waves)
+        int T = 0, C = 0;
+        if (team_geometry(a, &T, &C) && a.item_pipeline == 2) {
+            const int lds_bytes = (96 * 256 + 48 * 256 + 4 * 256) * 4 + 128;
+            const bool pipe = a.njobs * (a.B / (16 * T)) > C;      // several row blocks per workgroup
 #ifdef AVAE_DIAG
             if (a.ablate) {
-                if (!(a.ablate & ~(16 | 128 | 256))) return pipe ? launch_team(st, gru_fwd_team_kernel<true, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<true, false>, a, lds_bytes, C);
+                if (!(a.ablate & ~(16 | 128 | 256)) && T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<true, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<true, false, 4>, a, lds_bytes, C);
             } else
 #endif
-            return pipe ? launch_team(st, gru_fwd_team_kernel<false, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false>, a, lds_bytes, C);
+            {
+                if (T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4>, a, lds_bytes, C);
+                return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 2>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2>, a, lds_bytes, C);
+            }
         }
         // benchmark geometry (D = 512, two full 16-row chunks per workgroup): software-pipelined kernel
         if (a.D == 512 && a.rows_per_group == 32 && a.B % 32 == 0 && a.G * 32 == a.B && !a.ablate && a.item_pipeline) {
@@ -1514,11 +1533,12 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
         e = prepare_exchange(st, a, false); if (e != hipSuccess) return e;
-        int C = 0;
-        if (team_geometry(a, &C) && (a.njobs == 2 || C == 8) && !a.ablate && a.item_pipeline == 2) {
-            const int lds_bytes = (4 * 24 * 256 + kTeams * 4 * 256 + 64) * 4 + 64;
-            if (a.njobs * (a.B / 64) > C) return launch_team(st, gru_bwd_team_kernel<2, true>, a, lds_bytes, C);
-            return launch_team(st, gru_bwd_team_kernel<2, false>, a, lds_bytes, C);
+        int T = 0, C = 0;
+        if (team_geometry(a, &T, &C) && !a.ablate && a.item_pipeline == 2) {
+            const int lds_bytes = (4 * 24 * 256 + 16 * 256 + 64) * 4 + 64;
+            const bool pipe = a.njobs * (a.B / (16 * T)) > C;
+            if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4>, a, lds_bytes, C);
+            return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2>, a, lds_bytes, C);
         }
         return launch<false>(st, a, grid, true);
     }

@@ -231,10 +231,13 @@ def test_bench_scale_persistent_equals_stepwise():
         res.setdefault(mode, []).append((z, ev, g))
     (z1, e1, g1), (z0, e0, g0), (z2, e2, g2) = res[1][0], res[0][0], res[1][1]
     assert np.array_equal(z1, z0) and np.array_equal(z1, z2)
+    # decoder layers (one job, B = 256) run the 2-team form whose K is split over 8 waves instead of 4: same products,
+    # another summation tree, so per-token CE agrees to rounding (errt and the KL terms, encoder only, exactly)
     for a, b in zip(e1, e0):
-        assert np.array_equal(a, b)
+        assert np.allclose(a, b, rtol=0, atol=2e-5)
+    assert np.array_equal(e1[0], e0[0]) and np.array_equal(e1[2], e0[2])
     for a, b in zip(e1, e2):
-        assert np.array_equal(a, b)
+        assert np.array_equal(a, b)                    # persistent vs persistent (sc1-only exchange): bit for bit
     import torch
     d = (g1 - g0).norm() / g0.norm()
     assert float(d) < 1e-5, float(d)
