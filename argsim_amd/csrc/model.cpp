@@ -305,7 +305,15 @@ int gemm_tn_grad(avae_ctx* h, const float* A, int lda, const float* Bm, int ldb,
 {
     // a pair shares the ~768 workgroups: half the K split, half the float-atomic traffic per problem
     int s = (pair && h->cfg.compute_dtype == 0) ? grad_split(2 * M, N, K) : grad_split(M, N, K);
-    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, 0, pair);
+    // a small output over a long K (decode/out/kernel: 512 x 512 over 16 640 rows): 16 full tiles x 48 K slices would
+    // push 50 MB through the float atomics for 1 MB of output; 32x128 tiles x 12 slices push a quarter of that
+    int thin = 0;
+    if (!pair && h->cfg.compute_dtype == 0 && ((M + 127) / 128) * ((N + 127) / 128) <= 16 && K >= 4096) {
+        const int tt = ((M + 31) / 32) * ((N + 127) / 128);
+        s = std::max(1, std::min(768 / tt, K / 128));
+        thin = 1;
+    }
+    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, thin, pair);
 }
 
 void gru_geometry(int D, int njobs, int B, int* G, int* rpg)
