@@ -662,7 +662,7 @@ template <bool DIAG, bool PIPE, int T>
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
     const int ab = DIAG ? a.ablate : 0;                     // timing experiments / stamps: diagnostic instantiation only
-    constexpr int D = 512, HT = 32, KS = 16 / T, WK = D / KS, NQ = WK / 16, RB = 16 * T, TT = 64 * KS;
+    constexpr int D = 512, HT = 32, KS = 16 / T, WK = D / KS, NQ = WK / 16, RB = 16 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                                        // [wk KS][gate 3][q NQ][lane 64][4]    96 KB
     float* part = Wl + 96 * 256;                            // [team T][wk KS][gate 3][256]         48 KB
@@ -670,7 +670,15 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     unsigned* sync = reinterpret_cast<unsigned*>(hps + T * 256);      // [team T] barrier counters, [team T] exchange-ready epochs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int team = wave / KS, wk = wave % KS;
+    // wave -> (team, K-split index).  Waves w and w + 4 share a SIMD, and a team's K-split partners meet at a barrier
+    // every step: the FEWER SIMDs they sit on, the less arbitration skew that barrier pays (measured, gpurun_out/ab5.log,
+    // B = 256: partners on four SIMDs 7.76 ms of GRU per step, confined 7.38).  T = 4, one row block: each team on ONE
+    // SIMD (four independent chains, one per matrix pipe); several row blocks (PIPE): on TWO SIMDs, two teams per pair,
+    // so that a pipe always has a second team's MFMAs (B = 1024: 78.4 vs 80.3 ms per step); T = 2: each team on two SIMDs.
+    int team, wk;
+    if (T == 4 && !PIPE)     { team = wave & 3; wk = wave >> 2; }
+    else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }
+    else                     { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }
     const int n = lane & 15, kh = lane >> 4;
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = v;
     }
     if (tid < 2 * T) sync[tid] = 0u;
-    const int tt = tid % TT;                                // thread inside the team; its first 256 threads do the gate math
+    const int tt = wk * 64 + lane;                          // thread inside the team; its first 256 threads do the gate math
     const bool gate_thread = tt < 256;
     const int gn = tt & 15, gr = (tt >> 4) & 15;
     const int j = ht * 16 + gn;
@@ -1141,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 template <int NB, bool PIPE, int T>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves (see the forward)
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
-    constexpr int D = 512, HT = 32, PQ = 6, KS = 16 / T, WKB = 3 * D / KS, NH = WKB / 96, KB4 = 96 / KS, RB = 16 * T, TT = 64 * KS;
+    constexpr int D = 512, HT = 32, PQ = 6, KS = 16 / T, WKB = 3 * D / KS, NH = WKB / 96, KB4 = 96 / KS, RB = 16 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                                        // [wk KS][ks4 KB4][lane 64][4]    96 KB
     float* part = Wl + 96 * 256;                            // [team T][wk KS][256]            16 KB
@@ -1149,7 +1157,15 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     unsigned* sync = reinterpret_cast<unsigned*>(red + 64); // [team 4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int team = wave / KS, wk = wave % KS;
+    // wave -> (team, K-split index).  Waves w and w + 4 share a SIMD, and a team's K-split partners meet at a barrier
+    // every step: the FEWER SIMDs they sit on, the less arbitration skew that barrier pays (measured, gpurun_out/ab5.log,
+    // B = 256: partners on four SIMDs 7.76 ms of GRU per step, confined 7.38).  T = 4, one row block: each team on ONE
+    // SIMD (four independent chains, one per matrix pipe); several row blocks (PIPE): on TWO SIMDs, two teams per pair,
+    // so that a pipe always has a second team's MFMAs (B = 1024: 78.4 vs 80.3 ms per step); T = 2: each team on two SIMDs.
+    int team, wk;
+    if (T == 4 && !PIPE)     { team = wave & 3; wk = wave >> 2; }
+    else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }
+    else                     { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }
     const int n = lane & 15, kh = lane >> 4;
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
@@ -1164,7 +1180,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     }
     if (tid < T) sync[tid] = 0u;
     if (tid < 64) red[tid] = 0.f;
-    const int tt = tid % TT, gn = tt & 15, gr = (tt >> 4) & 15;
+    const int tt = wk * 64 + lane, gn = tt & 15, gr = (tt >> 4) & 15;
     const bool gate_thread = tt < 256;                        // the team's first 256 threads own one (row, unit) each
     const int j = ht * 16 + gn;
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads

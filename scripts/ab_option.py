@@ -11,9 +11,10 @@ m.step = 20000
 ids = torch.as_tensor(synth.batch(B, S, 8192, seed=0)).cuda()
 for i in range(5): m.train_step(ids, ids, seed=i)
 torch.cuda.synchronize()
-res = {0: [], 1: []}
-for rep in range(6):
-    for v in (1, 0):
+VALS = [int(x) for x in os.environ.get('VALS', '1,0').split(',')]
+res = {v: [] for v in VALS}
+for rep in range(int(os.environ.get('REPS', '6'))):
+    for v in VALS:
         m.set_option(key, v)
         for i in range(2): m.train_step(ids, ids, seed=i)
         torch.cuda.synchronize()
@@ -21,5 +22,6 @@ for rep in range(6):
         for i in range(15): m.train_step(ids, ids, seed=100 + i)
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / 15 * 1e3)
-for v in (1, 0):
+        print(key, v, '%.3f ms' % res[v][-1], 'losses', m.losses(), flush=True)
+for v in VALS:
     print(key, v, ' '.join('%.3f' % x for x in res[v]), ' median %.3f ms' % sorted(res[v])[len(res[v]) // 2])
