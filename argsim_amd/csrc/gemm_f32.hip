@@ -457,7 +457,8 @@ hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     if (!b_nc && (g.K & 3)) return hipErrorInvalidValue;
     if (b_nc && (g.N & 3)) return hipErrorInvalidValue;
     // (256x128 and 128x256 tiles were measured 5-20 % slower: 1 workgroup per CU cannot hide its own staging)
-    if (g.thin) launch_variant<1, 4, 1, 1>(st, a_mc, b_nc, g);
+    if (g.thin == 2) launch_variant<2, 2, 1, 1>(st, a_mc, b_nc, g);      // 64x64 tiles: 4x the tiles of the 128x128 form -> a quarter of the split-K slices
+    else if (g.thin) launch_variant<1, 4, 1, 1>(st, a_mc, b_nc, g);
     else        launch_variant<2, 2, 2, 2>(st, a_mc, b_nc, g);
     return hipGetLastError();
 }

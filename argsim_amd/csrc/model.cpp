@@ -303,17 +303,24 @@ int grad_split(int M, int N, int K)
 int gemm_tn_grad(avae_ctx* h, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
                  float alpha = 1.f, const int* dynk = nullptr, const Pair* pair = nullptr)
 {
-    // a pair shares the ~768 workgroups: half the K split, half the float-atomic traffic per problem
-    int s = (pair && h->cfg.compute_dtype == 0) ? grad_split(2 * M, N, K) : grad_split(M, N, K);
-    // a small output over a long K (decode/out/kernel: 512 x 512 over 16 640 rows): 16 full tiles x 48 K slices would
-    // push 50 MB through the float atomics for 1 MB of output; 32x128 tiles x 12 slices push a quarter of that
-    int thin = 0;
-    if (!pair && h->cfg.compute_dtype == 0 && ((M + 127) / 128) * ((N + 127) / 128) <= 16 && K >= 4096) {
-        const int tt = ((M + 31) / 32) * ((N + 127) / 128);
-        s = std::max(1, std::min(768 / tt, K / 128));
-        thin = 1;
+    if (h->cfg.compute_dtype != 0) {
+        const int s = grad_split(M, N, K);
+        return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, 0, pair);
     }
-    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, thin, pair);
+    // exact-fp32 kernel.  Few output tiles over a very long K: the K split's float atomics (~1.3 TB/s chip-wide, all
+    // workgroups at once at the end of one synchronous round) are the overhead, and they scale with tile bytes x
+    // slices.  64x64 tiles give four times the tiles, so a quarter of the slices fill the chip (decoder dW/dR pair,
+    // the two directions' dR: +6 %, gpurun_out/ab8.log); ~1536 workgroups = 6 per CU.  A pair shares them.
+    // A small output (decode/out/kernel, latent) uses 32x128 tiles.
+    const int np = pair ? 2 : 1;
+    const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
+    int thin = 2, tiles = ((M + 63) / 64) * ((N + 63) / 64) * np, target = 1536;
+    if (t128 * np > 96) { thin = 0; tiles = t128 * np; target = 768; }      // enough full tiles: 128x128 (measured: 64x64 loses 3-8 % there)
+    if (t128 <= 16) { thin = 1; tiles = ((M + 31) / 32) * ((N + 127) / 128) * np; target = 768; }
+    int s = (target + tiles / 2) / tiles;
+    s = std::max(1, std::min(s, std::max(1, K / 128)));
+    // (gradients were zero-filled: one slice may store, several add)
+    return gemm_raw(h, true, true, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, nullptr, 0, s, dynk, dynk ? 2 : 0, thin, pair);
 }
 
 void gru_geometry(int D, int njobs, int B, int* G, int* rpg)
@@ -472,9 +479,9 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
     AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1, true));
-    // (V x D output = 256 tiles: one workgroup per CU cannot overlap its own staging; K = N rows split 3 ways fills
-    //  three workgroups per CU; G was zero-filled above and the gather part is scatter-added at the end)
-    AV_TRY(gemm(h, true, true, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, nullptr, 0, grad_split(V, D, rt), w.ntok, 2));
+    // (V x D output over K = N rows: 1024 tiles of 64x64, one K slice, plain stores -- no atomics, deterministic; G was
+    //  zero-filled above and the gather part is scatter-added at the end)
+    AV_TRY(gemm_tn_grad(h, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, w.ntok));
     // out affine
     AV_TRY(gemm_tn_grad(h, w.hc, D, w.dho, D, G + h->oKout, D, D, D, rt, 1.f, w.ntok));
     AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));
@@ -832,8 +839,8 @@ int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const flo
                     int M, int N, int K, int lda, int ldb, int ldc, float alpha, int accumulate, int split_k)
 {
     if (!h) return 1;
-    // split_k == -1 selects the thin (32x128 tile) variant
-    return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : split_k, nullptr, 0, split_k < 0 ? 1 : 0);
+    // split_k == -1 selects the thin (32x128 tile) variant, 1000 + s the 64x64-tile variant with s K slices
+    return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : (split_k >= 1000 ? split_k - 1000 : split_k), nullptr, 0, split_k < 0 ? 1 : (split_k >= 1000 ? 2 : 0));
 }
 int avae_bucket_count(avae_handle h) { return h ? (int)h->buckets.size() : 0; }
 int avae_bucket_info(avae_handle h, int i, int64_t* offset, int64_t* count)

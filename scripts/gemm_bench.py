@@ -19,6 +19,11 @@ shapes = [  # name, a_mc, b_nc, M, N, K, split
     ('dE TN', 1, 1, 8192, 512, 16640, 1),
     ('enc dW TN split4', 1, 1, 3072, 1024, 16384, 4),
     ('dec dW TN split16', 1, 1, 1536, 512, 16640, 16),
+    ('dec dW TN 64x64 s4', 1, 1, 1536, 512, 16640, 1004),
+    ('dec dW TN 64x64 s8', 1, 1, 1536, 512, 16640, 1008),
+    ('dE TN 64x64 s1', 1, 1, 8192, 512, 16640, 1001),
+    ('enc dW TN 64x64 s1', 1, 1, 3072, 1024, 16384, 1001),
+    ('enc dW TN 64x64 s2', 1, 1, 3072, 1024, 16384, 1002),
     ('big TN 4096^2 x8192', 1, 1, 4096, 4096, 8192, 1),
     ('big NN 8192^2 x4096', 0, 1, 8192, 8192, 4096, 1),
 ]
