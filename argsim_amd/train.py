@@ -127,7 +127,7 @@ def profile(A, argv):
     child = [sys.executable, '-m', 'argsim_amd.train', '--profile-run', '--trial', A.trial, '--config', A.config,
              '--gpu', str(A.gpu), '--seed', str(A.seed)] + (['--ckpt', A.ckpt] if A.ckpt else [])
     tool = shutil.which('rocprofv3')
-    cmd = ([tool, '--kernel-trace', '--stats', '-d', out, '--'] if tool else []) + child
+    cmd = ([tool, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', out, '--'] if tool else []) + child
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)

@@ -328,3 +328,47 @@ def test_persistent_greedy_decode_equals_the_per_token_loop(b):
     assert m.decode(z, steps=40).shape == (b, 0)
     m.set_option('persistent', 0)
     assert m.decode(z, steps=40).shape == (b, 0)
+
+
+# ------------------------------------------------------------------------------------------ --profile / --save-tf
+def test_profile_flag_produces_a_kernel_profile_and_save_tf_writes_bundles(tmp_path):
+    """train.py --profile (src/train.py:76-82): the reference writes ONE traced run of the validation loss on valid[:32];
+    here a child process runs it under rocprofv3 (when present) and the per-kernel summary lands in <log>/<trial>_profile/.
+    --save-tf writes TF V2 checkpoint files beside the native one."""
+    import glob
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from argsim_amd import util_sp
+    from argsim_amd.util_np import vpack
+    rng = np.random.default_rng(0)
+    words = ['argument', 'stance', 'abortion', 'rights', 'gun', 'control', 'people', 'think', 'because', 'evidence',
+             'the', 'a', 'of', 'and', 'is', 'not', 'that', 'should', 'we', 'they', 'law', 'state', 'debate', 'claim']
+    lines = [' '.join(' '.join(rng.choice(words, int(rng.integers(4, 10)))) + '.' for _ in range(int(rng.integers(1, 4)))) for _ in range(300)]
+    d = tmp_path
+    (d / 'data').mkdir()
+    open(d / 'data' / 'train.txt', 'w').write('\n'.join(lines) + '\n')
+    vocab = util_sp.spm(str(d / 'data' / 'vocab'), str(d / 'data' / 'train.txt'), size=48)
+    val = [util_sp.encode_capped(vocab, t, cap=24) for t in lines[:40]]
+    np.save(d / 'data' / 'valid.npy', vpack(val, (len(val), max(map(len, val))), vocab.eos_id(), np.int32))
+    cfgj = {"paths": {"log": str(d / 'log'), "vocab": str(d / 'data' / 'vocab.model'), "train": str(d / 'data' / 'train.txt'),
+                      "valid": str(d / 'data' / 'valid.npy'), "ckpt": str(d / 'ckpt')},
+            "model": {"accelerate": 1e-4, "learn_rate": 1e-3, "dim_tgt": 48, "dim_emb": 64, "dim_rep": 16, "rnn_layers": 2,
+                      "bidirectional": True, "bidir_stacked": True, "attentive": False, "logit_use_embed": True},
+            "train": {"seed": 0, "max_len": 24, "batch_train": 16, "batch_valid": 12, "total_valid": 40}}
+    json.dump(cfgj, open(d / 'config.json', 'w'))
+    root = os.path.dirname(HERE)
+    # a fresh process: the profiler child must be started before anything has touched the GPU
+    res = subprocess.run([sys.executable, '-m', 'argsim_amd.train', '--config', str(d / 'config.json'), '--trial', 'p', '--profile',
+                          '--rounds', '1', '--steps-per-round', '10', '--valid-every', '10', '--save-tf'],
+                         cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0, out[-3000:]
+    rec = [json.loads(l) for l in out.splitlines() if l.startswith('{"valid32_forward_ms"')]
+    assert rec and rec[0]['valid32_forward_ms'] > 0 and rec[0]['classes']['gemm']['launches'] > 0
+    if shutil.which('rocprofv3'):
+        stats = glob.glob(str(d / 'log' / 'p_profile' / '**' / '*kernel_stats.csv'), recursive=True)
+        assert stats, out[-2000:]
+        assert 'gemm_f32' in open(stats[0]).read()
+    assert (d / 'ckpt' / 'p0.npz').exists() and (d / 'ckpt' / 'p0.index').exists() and glob.glob(str(d / 'ckpt' / 'p0.data-*'))
