@@ -372,3 +372,30 @@ def test_profile_flag_produces_a_kernel_profile_and_save_tf_writes_bundles(tmp_p
         assert stats, out[-2000:]
         assert 'gemm_f32' in open(stats[0]).read()
     assert (d / 'ckpt' / 'p0.npz').exists() and (d / 'ckpt' / 'p0.index').exists() and glob.glob(str(d / 'ckpt' / 'p0.data-*'))
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs[2] at full size
+def test_configs2_full_size_bf16_properties():
+    """BASELINE configs[2]: bf16 GEMM operands, batch 1024 x seq 128 (vocab 8k, latent 128) -- too large for any oracle,
+    so size-independent properties: rows are independent (the first 64 rows encode to the same z alone or inside the
+    full batch), every loss is finite, and the loss falls over a few Adam steps on one batch."""
+    import torch
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=0, dtype='bf16', dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    ids = synth.batch(1024, 128, 8192, ragged=True, seed=11)
+    z_all = m.encode(ids)
+    z_64 = m.encode(ids[:64])
+    assert z_all.shape == (1024, 128) and np.isfinite(z_all).all()
+    assert np.abs(z_all[:64] - z_64).max() <= 1e-5
+    dev = torch.as_tensor(ids).cuda()
+    first = last = None
+    for i in range(4):
+        m.train_step(dev, dev, seed=i)
+        lg, lk, lo = m.losses()
+        assert np.isfinite([lg, lk, lo]).all()
+        first = lo if first is None else first
+        last = lo
+    assert last < first
+    m.close()
