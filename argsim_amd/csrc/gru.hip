@@ -700,6 +700,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
     const int own_wk = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
+    const float* __restrict__ p_gi = J.gi;                  // read only, under no other name: its loads need not wait for this item's stores
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (KS * 3 * 256);
@@ -745,6 +746,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     };
     // sequence lengths of the rows this lane touches in the current item (A rows: n, gate rows: tid's row)
     int len_a = J.reverse ? a.lens[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * RB + team * 16 + gr] : 0;
+    const int len_p0 = J.reverse ? a.lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
     if constexpr (PIPE) next_frag(a.p_begin, 0, len_a);
     for (int p = a.p_begin; p < a.p_end; ++p) {
       for (int r = 0; r < tm.nrb; ++r, ++it) {
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
-        const float* gp = J.gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
+        const float* gp = p_gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
         float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f;
         if (gate_thread) { gi0 = gp[0]; gi1 = gp[1]; gi2 = gp[2]; }
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                     // still verifies its own fragment dword by dword below.
                     if (wk == 0) {
                         const int prow = row0 + 15;
-                        const int plen = J.reverse ? a.lens[prow] : 0;
+                        const int plen = len_p0;                     // (!PIPE: one row block, fetched once before the loop)
                         const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
                         SpinGuard sg;
                         while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
@@ -1146,9 +1148,13 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 // probe of the register-form D = 512 path above, with a ring of NB 24-register pieces (128-register budget at 4 waves
 // per SIMD) whose first NB pieces are in flight before the MFMAs start.  A job with dh0 (decoder layers) gets the
 // tail item p = -1: dh0 = carry + dgh_0 R.  Teams synchronise through monotonic LDS counters, never s_barrier.
-template <int NB, bool PIPE, int T>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves (see the forward)
+template <int NB, bool PIPE, int T, bool DIAG = false>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves (see the forward)
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
+    // diagnostic phase stamps (DIAG instantiation only): [0] top loads [1] probe + first pieces [2] operand stream + MFMAs
+    // [3] barrier 1 [4] partial write + prefetch [5] barrier 2 [6] gate derivatives + stores
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ULL;
+#define BSTAMP(i) do { if constexpr (DIAG) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
     constexpr int D = 512, HT = 32, PQ = 6, KS = 16 / T, WKB = 3 * D / KS, NH = WKB / 96, KB4 = 96 / KS, RB = 16 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                                        // [wk KS][ks4 KB4][lane 64][4]    96 KB
@@ -1193,6 +1199,14 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         else if (tq == 1) __builtin_amdgcn_s_setprio(2);
         else if (tq == 2) __builtin_amdgcn_s_setprio(1);
     }
+    // The saved activations are only read and dgi is only written here, never through another name: saying so lets the
+    // compiler issue the next item's loads without first waiting for this item's stores (without it every item paid
+    // two to three exposed memory round trips: hipcc orders any load behind any earlier store it cannot prove
+    // disjoint with s_waitcnt vmcnt(0)).
+    const float* __restrict__ p_sv = J.sv;
+    const float* __restrict__ p_hp = J.hp;
+    const float* __restrict__ p_do = J.dh_out;
+    float* __restrict__ p_dgi = J.dgi;
     const unsigned long long pa = (unsigned long long)J.dgh;
     const i32x4 srd = {(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
     float sb_r = 0.f, sb_u = 0.f, sb_n = 0.f, sb_nr = 0.f;
@@ -1200,6 +1214,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int p_last = want_dh0 ? -1 : a.p_begin;             // p == -1: only dh0 = carry + dgh_0 R'
     int done = 0;
     unsigned it = 0;
+    float carry_reg = 0.f;                                    // !PIPE: dH_{p+1} u_{p+1} of this thread's (row, unit)
     u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
@@ -1232,6 +1247,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         }
     };
     int len_a = J.reverse ? a.lens[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * RB + team * 16 + gr] : 0;
+    const int len_p0 = J.reverse ? a.lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
     if constexpr (PIPE) next_head(a.p_end - 1, 0, len_a);
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
       for (int r = 0; r < tm.nrb; ++r, ++it) {
@@ -1252,16 +1268,20 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         const size_t rix = (size_t)pos_map(p < 0 ? 0 : p, len_g, J.reverse) * B + grow;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
         if (p >= 0 && gate_thread) {
-            sv = *reinterpret_cast<const float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4);
-            s_hp = J.hp[rix * D + j];
-            s_do = J.dh_out ? J.dh_out[rix * a.ldh + j] : 0.f;
+            sv = *reinterpret_cast<const float4*>(p_sv + (rix * HT + ht) * 64 + gn * 4);
+            s_hp = p_hp[rix * D + j];
+            s_do = p_do ? p_do[rix * a.ldh + j] : 0.f;
         }
         // dH_{p+1} u_{p+1} of this (row, unit): written by this same thread one step ago
         // (PIPE: fetched here, ahead of the next item's operand loads -- memory returns in order, so a load issued
         //  behind them would wait for them)
+        // One row block (!PIPE): the same thread owns the same (row, unit) at every step, so the carry lives in a register
+        // for the whole launch (memory only at its ends).
         float* carryp = J.carry + (size_t)grow * D + j;
         float s_carry = 0.f;
         if constexpr (PIPE) { if (have_next && gate_thread) s_carry = *carryp; }
+        else { if (done == 0 && have_next && gate_thread) carry_reg = *carryp; }
+        BSTAMP(0);
         // (2)+(3) A operand = dgh_{p+1} of the team's 16 rows, this wave's K quarter, in four 96-float pieces
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         if (have_next) {
@@ -1295,7 +1315,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             };
             auto probe = [&](SpinGuard& sg) __attribute__((always_inline)) {
                 // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
-                const int len_p = J.reverse ? a.lens[row0 + 15] : 0;
+                const int len_p = PIPE ? (J.reverse ? a.lens[row0 + 15] : 0) : len_p0;      // (one row block: fetched once, before the loop)
                 const float* pp = J.dgh + ((size_t)pos_map(p + 1, len_p, J.reverse) * B + row0 + 15) * a.ldg + (lane & 31) * 48 + 47;
                 while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
             };
@@ -1304,6 +1324,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 if (poll) probe(sg);
                 head(voff);
             }
+            BSTAMP(1);
             for (;;) {
                 const bool bad = pass();
                 if (!poll || !bad || sg.expired(a.err)) break;
@@ -1320,10 +1341,14 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             if (p2 >= p_last) next_head(p2, r2, len2);
             __builtin_amdgcn_sched_barrier(0);
         }
+        BSTAMP(2);
         // every wave of the team has finished READING the previous item's partial sums, then publish this item's
         if (it > 0) { epoch += KS; team_barrier(tsync, epoch); }
+        BSTAMP(3);
         *reinterpret_cast<f32x4*>(tpart + wk * 256 + lane * 4) = sum;
+        BSTAMP(4);
         epoch += KS; team_barrier(tsync, epoch);
+        BSTAMP(5);
         // (4) gate derivatives: the team's 256 threads, one (row, unit) each; exchanged stores first
         if (gate_thread) {
             const int pidx = ((gr >> 2) * 16 + gn) * 4 + (gr & 3);
@@ -1332,7 +1357,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             for (int k = 0; k < KS; ++k) s4[k & 3] += tpart[k * 256 + pidx];
             float carried = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             if constexpr (PIPE) carried += s_carry;
-            else if (have_next) carried += *carryp;
+            else if (have_next) carried += carry_reg;
             if (p < 0) { J.dh0[(size_t)grow * D + j] = carried; len_a = len2; len_g = len2g; continue; }
             const float dH = carried + s_do;
             const float r_ = sv.x, u = sv.y, nn = sv.z;
@@ -1343,14 +1368,26 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
             if (fast) { dgh[0] = x0; dgh[1] = x1; dgh[2] = x2; }
             else { store4_sc1(dgh, x0); store4_sc1(dgh + 1, x1); store4_sc1(dgh + 2, x2); }
-            *carryp = dH * u;
-            float* dgi = J.dgi + rix * a.ldg + ht * 48 + gn * 3;
+            if constexpr (PIPE) *carryp = dH * u; else carry_reg = dH * u;
+            float* dgi = p_dgi + rix * a.ldg + ht * 48 + gn * 3;
             dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
         len_a = len2; len_g = len2g;
+        BSTAMP(6);
       }
     }
+    if constexpr (!PIPE) {     // a later launch over earlier steps continues from memory
+        if (gate_thread && p_last >= 0 && a.p_end - 1 >= p_last) J.carry[(size_t)(tm.slot * RB + team * 16 + gr) * D + j] = carry_reg;
+    }
+    if constexpr (DIAG) {
+        if (tt == 0 && a.stamps) {
+            for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + 16 + i, ph[i]);
+            atomicAdd(a.stamps + 16 + 8, (unsigned long long)(a.p_end - a.p_begin));
+            atomicAdd(a.stamps + 16 + 10, 1ULL);
+        }
+    }
+#undef BSTAMP
     // bias gradients: all rows of the workgroup into LDS, then one atomic per (gate, unit)
     if (J.dbW || J.dbR) {
         atomicAdd(&red[gn], sb_r); atomicAdd(&red[16 + gn], sb_u); atomicAdd(&red[32 + gn], sb_n); atomicAdd(&red[48 + gn], sb_nr);
@@ -1550,9 +1587,15 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
     if (persistent) {
         e = prepare_exchange(st, a, false); if (e != hipSuccess) return e;
         int T = 0, C = 0;
-        if (team_geometry(a, &T, &C) && !a.ablate && a.item_pipeline == 2) {
+        if (team_geometry(a, &T, &C) && !(a.ablate & ~128) && a.item_pipeline == 2) {
             const int lds_bytes = (4 * 24 * 256 + 16 * 256 + 64) * 4 + 64;
             const bool pipe = a.njobs * (a.B / (16 * T)) > C;
+#ifdef AVAE_DIAG
+            if (a.ablate & 128) {
+                if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4, true>, a, lds_bytes, C);
+                return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2, true>, a, lds_bytes, C);
+            }
+#endif
             if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4>, a, lds_bytes, C);
             return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2>, a, lds_bytes, C);
         }
