@@ -99,16 +99,20 @@ __device__ __forceinline__ void put(float* c, float v)
 template <int TM, int TN, int WN, int MODE>
 __device__ __forceinline__ void epilogue_full(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int h, int l31, bool add_bias)
 {
+    // (the bias values are fetched before the first store: a load issued between the stores makes hipcc wait for it
+    //  with vmcnt(0), i.e. for every store before it -- one exposed store round trip per 32x32 tile)
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = add_bias ? g.bias[n0 + 32 * (wn * TN + j) + l31] : 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + 32 * (wn * TN + j) + l31;
-        const float bv = add_bias ? g.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float* c = g.C + (size_t)(m0 + 32 * (wm * TM + i) + 4 * h) * g.ldc + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                put<MODE>(c + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldc, g.alpha * acc[i][j][r] + bv);
+                put<MODE>(c + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldc, g.alpha * acc[i][j][r] + bv[j]);
         }
     }
 }

@@ -701,6 +701,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
     const int own_wk = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
     const float* __restrict__ p_gi = J.gi;                  // read only, under no other name: its loads need not wait for this item's stores
+    float* __restrict__ p_svw = J.sv;                       // written only, under no other name: later loads need not wait for them
+    float* __restrict__ p_hpw = J.hp;
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (KS * 3 * 256);
@@ -859,8 +861,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             const size_t rix = (size_t)gpos * B + grow;
             float* hdst = J.hs + rix * a.ldh + j;
             if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
-            if (J.sv) *reinterpret_cast<float4*>(J.sv + (rix * HT + ht) * 64 + gn * 4) = make_float4(r_, u, nn, gh[2]);
-            if (J.hp) J.hp[rix * D + j] = hprev;
+            if (p_svw) *reinterpret_cast<float4*>(p_svw + (rix * HT + ht) * 64 + gn * 4) = make_float4(r_, u, nn, gh[2]);
+            if (p_hpw) p_hpw[rix * D + j] = hprev;
         }
         len_a = len2; len_g = len2g;
         TSTAMP(3);
