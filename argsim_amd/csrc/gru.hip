@@ -1217,6 +1217,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     int done = 0;
     unsigned it = 0;
     float carry_reg = 0.f;                                    // !PIPE: dH_{p+1} u_{p+1} of this thread's (row, unit)
+    float carry_r0 = 0.f, carry_r1 = 0.f, carry_r2 = 0.f, carry_r3 = 0.f;      // PIPE: the same, per row block
     u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
@@ -1281,7 +1282,10 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         // for the whole launch (memory only at its ends).
         float* carryp = J.carry + (size_t)grow * D + j;
         float s_carry = 0.f;
-        if constexpr (PIPE) { if (have_next && gate_thread) s_carry = *carryp; }
+        if constexpr (PIPE) {       // up to four row blocks: one register each, selected by the (uniform) block index
+            if (done == 0 && have_next && gate_thread) { const float c0 = *carryp; if (r == 0) carry_r0 = c0; else if (r == 1) carry_r1 = c0; else if (r == 2) carry_r2 = c0; else carry_r3 = c0; }
+            s_carry = r == 0 ? carry_r0 : (r == 1 ? carry_r1 : (r == 2 ? carry_r2 : carry_r3));
+        }
         else { if (done == 0 && have_next && gate_thread) carry_reg = *carryp; }
         BSTAMP(0);
         // (2)+(3) A operand = dgh_{p+1} of the team's 16 rows, this wave's K quarter, in four 96-float pieces
@@ -1370,7 +1374,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
             if (fast) { dgh[0] = x0; dgh[1] = x1; dgh[2] = x2; }
             else { store4_sc1(dgh, x0); store4_sc1(dgh + 1, x1); store4_sc1(dgh + 2, x2); }
-            if constexpr (PIPE) *carryp = dH * u; else carry_reg = dH * u;
+            if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
+            else carry_reg = dH * u;
             float* dgi = p_dgi + rix * a.ldg + ht * 48 + gn * 3;
             dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
@@ -1379,8 +1384,11 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         BSTAMP(6);
       }
     }
-    if constexpr (!PIPE) {     // a later launch over earlier steps continues from memory
-        if (gate_thread && p_last >= 0 && a.p_end - 1 >= p_last) J.carry[(size_t)(tm.slot * RB + team * 16 + gr) * D + j] = carry_reg;
+    if (gate_thread && p_last >= 0 && a.p_end - 1 >= p_last) {      // a later launch over earlier steps continues from memory
+        if constexpr (!PIPE) J.carry[(size_t)(tm.slot * RB + team * 16 + gr) * D + j] = carry_reg;
+        else
+            for (int r = 0; r < tm.nrb; ++r)
+                J.carry[(size_t)((tm.slot + r * tm.cpj) * RB + team * 16 + gr) * D + j] = r == 0 ? carry_r0 : (r == 1 ? carry_r1 : (r == 2 ? carry_r2 : carry_r3));
     }
     if constexpr (DIAG) {
         if (tt == 0 && a.stamps) {
@@ -1521,7 +1529,7 @@ static bool team_geometry(const GruArgs& a, int* T, int* C)
         if (np < 8) continue;                       // would leave CUs idle: try smaller blocks
         if (np == 8) { *T = t; *C = 8; return true; }
         const int cpj = 8 / a.njobs;
-        if (nrbj % cpj) continue;
+        if (nrbj % cpj || nrbj / cpj > 4) continue;      // (at most four row blocks per workgroup: the backward keeps one carry register per block)
         *T = t; *C = 8;
         return true;
     }
