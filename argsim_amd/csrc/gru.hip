@@ -126,6 +126,13 @@ __device__ __forceinline__ void frag_issue(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_
 #pragma unroll
     for (int q = 0; q < NQ; ++q) v[q] = load16_sc1(rs, off + 64u * q);
 }
+// the same with a run-time (wave-uniform) distance between the pieces: it travels in the scalar offset operand
+template <int NQ>
+__device__ __forceinline__ void frag_issue(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_t rs, unsigned off, unsigned qstride)
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (int)(qstride * q), 16);
+}
 template <int NQ>
 __device__ __forceinline__ bool frag_bad(const u32x4 (&v)[NQ])
 {
@@ -141,6 +148,14 @@ __device__ __forceinline__ void frag_ensure(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc
     if (frag_bad<NQ>(v)) {
         SpinGuard sg;
         do { frag_issue<NQ>(v, rs, off); } while (frag_bad<NQ>(v) && !sg.expired(err));
+    }
+}
+template <int NQ>
+__device__ __forceinline__ void frag_ensure(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_t rs, unsigned off, int* err, unsigned qstride)
+{
+    if (frag_bad<NQ>(v)) {
+        SpinGuard sg;
+        do { frag_issue<NQ>(v, rs, off, qstride); } while (frag_bad<NQ>(v) && !sg.expired(err));
     }
 }
 
@@ -161,6 +176,20 @@ __device__ __forceinline__ void asm_issue6(u32x4 (&v)[6], unsigned voff, i32x4 s
                  "buffer_load_dwordx4 %5, %6, %7, 0 offen offset:%c13 sc1"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
                  : "v"(voff), "s"(srd), "i"(OFF), "i"(OFF + 64), "i"(OFF + 128), "i"(OFF + 192), "i"(OFF + 256), "i"(OFF + 320)
+                 : "memory");
+}
+// the same six loads from the tiled exchange: 1 KB between consecutive 16-float groups (soffset carries what the 12-bit
+// immediate cannot)
+__device__ __forceinline__ void asm_issue6x(u32x4 (&v)[6], unsigned voff, i32x4 srd, int soff0, int soff1)
+{
+    asm volatile("buffer_load_dwordx4 %0, %6, %7, %8 offen offset:0 sc1\n\t"
+                 "buffer_load_dwordx4 %1, %6, %7, %8 offen offset:1024 sc1\n\t"
+                 "buffer_load_dwordx4 %2, %6, %7, %8 offen offset:2048 sc1\n\t"
+                 "buffer_load_dwordx4 %3, %6, %7, %8 offen offset:3072 sc1\n\t"
+                 "buffer_load_dwordx4 %4, %6, %7, %9 offen offset:0 sc1\n\t"
+                 "buffer_load_dwordx4 %5, %6, %7, %9 offen offset:1024 sc1"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                 : "v"(voff), "s"(srd), "s"(soff0), "s"(soff1)
                  : "memory");
 }
 template <int N>
@@ -626,6 +655,25 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
 // s_barrier, which would put the four chains in lock step).  Exchange between workgroups: the same in-band
 // sentinel protocol as above.
 
+// ---- tiled exchange (team kernels).  The MFMA A operand puts 16 different batch rows in 16 adjacent lanes.  Read from
+// a row-major (pos, row, k) buffer, every lane of a 16-byte load touches another cache line (rows are 2-6 KB apart) and
+// the CU's texture addresser spends ~64 cycles per load instruction: TA_BUSY was 93 % of the backward kernel and 48 %
+// of the forward (gpurun_out/pp1_p5), the real limiter of the step.  The exchanged operand therefore lives in a
+// scratch buffer in fragment order -- element (pos, row, k) at
+//     X[(((pos * B/16 + row/16) * K/4 + k/4) * 16 + row%16) * 4 + k%4]
+// -- so that one load instruction of a wave reads 1 KB of contiguous memory (lane (n, kh): 16 bytes at n*16 + kh*256).
+// The row-major hs / dgh the GEMMs consume are written beside it with plain stores and are no longer polled.
+// (float index; a job's buffer is below 2^32 bytes -- team_geometry checks -- so 32-bit arithmetic is exact)
+__device__ __forceinline__ unsigned xch_index(int pos, int row, int k, int B, int K)
+{
+    return ((((unsigned)pos * (unsigned)(B >> 4) + (unsigned)(row >> 4)) * (unsigned)(K >> 2) + (unsigned)(k >> 2)) * 16u + (unsigned)(row & 15)) * 4u + (unsigned)(k & 3);
+}
+// byte offset of lane (n, kh)'s 16 bytes of chunk kc0 + kh, rows row0 .. row0+15 (row0 % 16 == 0) at position pos
+__device__ __forceinline__ unsigned xch_lane_offset(int pos, int row0, int kc0, int n, int kh, int B, int K)
+{
+    return ((((unsigned)pos * (unsigned)(B >> 4) + (unsigned)(row0 >> 4)) * (unsigned)(K >> 2) + (unsigned)(kc0 + kh)) * 16u + (unsigned)n) * 16u;
+}
+
 __device__ __forceinline__ void team_barrier(unsigned* word, unsigned target)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's LDS traffic is done
@@ -703,7 +751,9 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const float* __restrict__ p_gi = J.gi;                  // read only, under no other name: its loads need not wait for this item's stores
     float* __restrict__ p_svw = J.sv;                       // written only, under no other name: later loads need not wait for them
     float* __restrict__ p_hpw = J.hp;
-    const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(J.hs), rs_h0 = make_rsrc(J.h0 ? J.h0 : J.hs);
+    float* __restrict__ p_hsw = J.hs;
+    float* const xh = a.xbuf + (size_t)tm.jb * a.S * B * D;          // this job's exchange buffer (tiled, sentinel-filled)
+    const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(xh), rs_h0 = make_rsrc(J.h0 ? J.h0 : xh);
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (KS * 3 * 256);
     float* thps = hps + team * 256;
@@ -731,16 +781,17 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     // matrix-pipe rate instead of at the chain latency).
     unsigned it = 0;                                          // items done so far (monotonic; LDS epochs derive from it)
     u32x4 ra[NQ];
-    auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first 16-byte piece
-        const int row = row0 + n;
-        const unsigned o = (p == 0) ? (unsigned)((size_t)row * D * 4)
-                                    : (unsigned)((((size_t)pos_map(p - 1, len_a, J.reverse) * B + row) * a.ldh) * 4);
-        return o + (wk * WK + 4 * kh) * 4;
+    // byte offset of this lane's first 16-byte piece: step 0 reads the row-major h0 (pieces 64 B apart), later steps
+    // the tiled exchange (pieces 1 KB apart)
+    auto a_offset = [&](int p, int row0, int len_a) -> unsigned {
+        if (p == 0) return (unsigned)((size_t)(row0 + n) * D * 4) + (wk * WK + 4 * kh) * 4;
+        return xch_lane_offset(pos_map(p - 1, len_a, J.reverse), row0, wk * (WK / 4), n, kh, B, D);
     };
+    auto q_stride = [&](int p) -> unsigned { return p == 0 ? 64u : 1024u; };
     auto next_frag = [&](int p2, int r2, int len2) __attribute__((always_inline)) {   // PIPE: issue (or zero) the fragment of item (p2, r2)
         if (p2 > 0 || J.h0 != nullptr) {
             const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
-            frag_issue<NQ>(ra, (p2 == 0) ? rs_h0 : rs_hs, a_offset(p2, row2, len2));
+            frag_issue<NQ>(ra, (p2 == 0) ? rs_h0 : rs_hs, a_offset(p2, row2, len2), q_stride(p2));
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
@@ -785,7 +836,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                     if (wk == 0) {
                         const int prow = row0 + 15;
                         const int plen = len_p0;                     // (!PIPE: one row block, fetched once before the loop)
-                        const float* pp = J.hs + ((size_t)pos_map(p - 1, plen, J.reverse) * B + prow) * a.ldh + (lane & 31) * 16 + 15;
+                        const float* pp = xh + xch_index(pos_map(p - 1, plen, J.reverse), prow, (lane & 31) * 16 + 15, B, D);
                         SpinGuard sg;
                         while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
                         if (lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -793,9 +844,9 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                         while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                frag_issue<NQ>(ra, rs, aoff);
+                frag_issue<NQ>(ra, rs, aoff, q_stride(p));
             }
-            if (poll) frag_ensure<NQ>(ra, rs, aoff, a.err);
+            if (poll) frag_ensure<NQ>(ra, rs, aoff, a.err, q_stride(p));
         } else if constexpr (!PIPE) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
@@ -859,8 +910,9 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             const float r_ = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r_ * gh[2]);
             const float hnew = (1.f - u) * nn + u * hprev;
             const size_t rix = (size_t)gpos * B + grow;
-            float* hdst = J.hs + rix * a.ldh + j;
-            if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
+            float* xdst = xh + xch_index(gpos, grow, j, B, D);      // exchanged store first
+            if (fast) *xdst = not_sentinel(hnew); else store4_sc1(xdst, not_sentinel(hnew));
+            p_hsw[rix * a.ldh + j] = hnew;                          // the row-major copy the GEMMs and the next layer read
             if (p_svw) *reinterpret_cast<float4*>(p_svw + (rix * HT + ht) * 64 + gn * 4) = make_float4(r_, u, nn, gh[2]);
             if (p_hpw) p_hpw[rix * D + j] = hprev;
         }
@@ -1191,7 +1243,16 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int tt = wk * 64 + lane, gn = tt & 15, gr = (tt >> 4) & 15;
     const bool gate_thread = tt < 256;                        // the team's first 256 threads own one (row, unit) each
     const int j = ht * 16 + gn;
+    unsigned long long tp0 = 0, tp1 = 0;
+    if constexpr (DIAG) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tp0 = __builtin_amdgcn_s_memrealtime(); }
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
+    if constexpr (DIAG) {
+        tp1 = __builtin_amdgcn_s_memrealtime();
+        if (tt == 0 && a.stamps && ((a.ablate & 256) ? T == 2 : T == 4)) {
+            atomicAdd(a.stamps + 16 + 11, tp0 - tprev);     // weights -> LDS
+            atomicAdd(a.stamps + 16 + 12, tp1 - tp0);       // same-XCD rendezvous
+        }
+    }
     float* tpart = part + team * (KS * 256);
     unsigned* tsync = sync + team;
     unsigned epoch = 0;
@@ -1209,25 +1270,29 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const float* __restrict__ p_hp = J.hp;
     const float* __restrict__ p_do = J.dh_out;
     float* __restrict__ p_dgi = J.dgi;
-    const unsigned long long pa = (unsigned long long)J.dgh;
+    float* __restrict__ p_dghw = J.dgh;
+    float* p_dh0 = J.dh0;
+    float* p_carry = J.carry;
+    const int* p_lens = a.lens;
+    int* p_err = a.err;
+    const int j_rev = J.reverse, ldg = a.ldg, ldh = a.ldh;
+    float* const xg = a.xbuf + (size_t)tm.jb * S * B * (3 * D);       // this job's exchange buffer (tiled, sentinel-filled)
+    const unsigned long long pa = (unsigned long long)xg;
     const i32x4 srd = {(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
     float sb_r = 0.f, sb_u = 0.f, sb_n = 0.f, sb_nr = 0.f;
-    const bool want_dh0 = (J.dh0 != nullptr) && a.p_begin == 0;
+    const bool want_dh0 = (p_dh0 != nullptr) && a.p_begin == 0;
     const int p_last = want_dh0 ? -1 : a.p_begin;             // p == -1: only dh0 = carry + dgh_0 R'
     int done = 0;
     unsigned it = 0;
     float carry_reg = 0.f;                                    // !PIPE: dH_{p+1} u_{p+1} of this thread's (row, unit)
     float carry_r0 = 0.f, carry_r1 = 0.f, carry_r2 = 0.f, carry_r3 = 0.f;      // PIPE: the same, per row block
     u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
-    const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(J.dgh);
+    const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(xg);
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
-        return (unsigned)((((size_t)pos_map(p + 1, len_a, J.reverse) * B + row0 + n) * a.ldg + wk * WKB) * 4) + 16 * kh;
+        return xch_lane_offset(pos_map(p + 1, len_a, j_rev), row0, wk * (WKB / 4), n, kh, B, 3 * D);
     };
     auto issue_piece = [&](int piece, u32x4 (&dst)[PQ], unsigned vo) __attribute__((always_inline)) {
-        if (piece == 0) asm_issue6<0>(dst, vo, srd);
-        if (piece == 1) asm_issue6<384>(dst, vo, srd);
-        if (piece == 2) asm_issue6<768>(dst, vo, srd);
-        if (piece == 3) asm_issue6<1152>(dst, vo, srd);
+        asm_issue6x(dst, vo, srd, 6144 * piece, 6144 * piece + 4096);       // a piece = 96 floats of K = 24 chunks of 256 B
     };
     // the first NB pieces go in flight BEFORE the item's MFMAs, the rest behind the MFMAs of the piece whose
     // registers they reuse
@@ -1246,41 +1311,47 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 #pragma unroll
             for (int s0 = 0; s0 < NB && s0 < NH; ++s0)
 #pragma unroll
-                for (int q = 0; q < PQ; ++q) hv[s0][q] = load16_sc1(rs_dgh, vo2 + 384u * s0 + 64u * q);
+                for (int q = 0; q < PQ; ++q) hv[s0][q] = load16_sc1(rs_dgh, vo2 + 6144u * s0 + 1024u * q);
         }
     };
-    int len_a = J.reverse ? a.lens[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * RB + team * 16 + gr] : 0;
-    const int len_p0 = J.reverse ? a.lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
+    int len_a = j_rev ? p_lens[tm.slot * RB + team * 16 + n] : 0, len_g = j_rev ? p_lens[tm.slot * RB + team * 16 + gr] : 0;
+    const int len_p0 = j_rev ? p_lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
     if constexpr (PIPE) next_head(a.p_end - 1, 0, len_a);
     for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
       for (int r = 0; r < tm.nrb; ++r, ++it) {
         const int row0 = (tm.slot + r * tm.cpj) * RB + team * 16;
-        const int grow = row0 + gr;
+        // (the compiler would otherwise keep a dozen loop-invariant 64-bit per-lane addresses alive across the MFMA
+        //  phase and spill them at 128 VGPRs; hidden behind an empty asm the lane's unit / row are re-derived per item)
+        int gn_l = gn, gr_l = gr, ln_l = lane;
+        asm volatile("" : "+v"(gn_l), "+v"(gr_l), "+v"(ln_l));
+        const int grow = row0 + gr_l, j_l = ht * 16 + gn_l;
         const bool have_next = p + 1 < S;
-        const bool poll = done > 0;
+        const bool poll = done > 0 && !(DIAG && (a.ablate & 16));      // ablate 16 (diagnostic build): no waiting, wrong results
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
         const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p - 1;
         int len2 = len_a, len2g = len_g;
         if constexpr (PIPE) {
-            if (J.reverse && p2 >= p_last) {
+            if (j_rev && p2 >= p_last) {
                 const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
-                len2 = a.lens[row2 + n]; len2g = a.lens[row2 + gr];
+                len2 = p_lens[row2 + n]; len2g = p_lens[row2 + gr];
             }
         }
+        BSTAMP(7);
         // (1) exchange-independent loads of the gate phase
-        const size_t rix = (size_t)pos_map(p < 0 ? 0 : p, len_g, J.reverse) * B + grow;
+        const int gpos = pos_map(p < 0 ? 0 : p, len_g, j_rev);
+        const size_t rix = (size_t)gpos * B + grow;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
         if (p >= 0 && gate_thread) {
-            sv = *reinterpret_cast<const float4*>(p_sv + (rix * HT + ht) * 64 + gn * 4);
-            s_hp = p_hp[rix * D + j];
-            s_do = p_do ? p_do[rix * a.ldh + j] : 0.f;
+            sv = *reinterpret_cast<const float4*>(p_sv + (rix * HT + ht) * 64 + gn_l * 4);
+            s_hp = p_hp[rix * D + j_l];
+            s_do = p_do ? p_do[rix * ldh + j_l] : 0.f;
         }
         // dH_{p+1} u_{p+1} of this (row, unit): written by this same thread one step ago
         // (PIPE: fetched here, ahead of the next item's operand loads -- memory returns in order, so a load issued
         //  behind them would wait for them)
         // One row block (!PIPE): the same thread owns the same (row, unit) at every step, so the carry lives in a register
         // for the whole launch (memory only at its ends).
-        float* carryp = J.carry + (size_t)grow * D + j;
+        float* carryp = p_carry + (size_t)grow * D + j_l;
         float s_carry = 0.f;
         if constexpr (PIPE) {       // up to four row blocks: one register each, selected by the (uniform) block index
             if (done == 0 && have_next && gate_thread) { const float c0 = *carryp; if (r == 0) carry_r0 = c0; else if (r == 1) carry_r1 = c0; else if (r == 2) carry_r2 = c0; else carry_r3 = c0; }
@@ -1321,9 +1392,9 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             };
             auto probe = [&](SpinGuard& sg) __attribute__((always_inline)) {
                 // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
-                const int len_p = PIPE ? (J.reverse ? a.lens[row0 + 15] : 0) : len_p0;      // (one row block: fetched once, before the loop)
-                const float* pp = J.dgh + ((size_t)pos_map(p + 1, len_p, J.reverse) * B + row0 + 15) * a.ldg + (lane & 31) * 48 + 47;
-                while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                const int len_p = PIPE ? (j_rev ? p_lens[row0 + 15] : 0) : len_p0;      // (one row block: fetched once, before the loop)
+                const float* pp = xg + xch_index(pos_map(p + 1, len_p, j_rev), row0 + 15, (ln_l & 31) * 48 + 47, B, 3 * D);
+                while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(p_err)) { }
             };
             SpinGuard sg;
             if constexpr (!PIPE) {
@@ -1333,7 +1404,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             BSTAMP(1);
             for (;;) {
                 const bool bad = pass();
-                if (!poll || !bad || sg.expired(a.err)) break;
+                if (!poll || !bad || sg.expired(p_err)) break;
                 probe(sg);
                 head(voff);
             }
@@ -1364,19 +1435,26 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             float carried = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             if constexpr (PIPE) carried += s_carry;
             else if (have_next) carried += carry_reg;
-            if (p < 0) { J.dh0[(size_t)grow * D + j] = carried; len_a = len2; len_g = len2g; continue; }
+            if (p < 0) { p_dh0[(size_t)grow * D + j_l] = carried; len_a = len2; len_g = len2g; continue; }
             const float dH = carried + s_do;
             const float r_ = sv.x, u = sv.y, nn = sv.z;
             const float dn = dH * (1.f - u) * (1.f - nn * nn);
             const float du = dH * (s_hp - nn) * u * (1.f - u);
             const float dr = dn * sv.w * r_ * (1.f - r_);
-            float* dgh = J.dgh + rix * a.ldg + ht * 48 + gn * 3;
             const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
-            if (fast) { dgh[0] = x0; dgh[1] = x1; dgh[2] = x2; }
-            else { store4_sc1(dgh, x0); store4_sc1(dgh + 1, x1); store4_sc1(dgh + 2, x2); }
+            {   // exchanged stores first (tiled buffer: three dwords, possibly in two 16-byte chunks)
+                const int k0 = ht * 48 + gn_l * 3;                   // k0 % 4 == (gn * 3) % 4; the next k is 1 float on, or 61 across a chunk
+                const unsigned i0 = xch_index(gpos, grow, k0, B, 3 * D);
+                const unsigned i1 = i0 + (((k0 & 3) == 3) ? 61u : 1u), i2 = i1 + ((((k0 + 1) & 3) == 3) ? 61u : 1u);
+                float* q0 = xg + i0; float* q1 = xg + i1; float* q2 = xg + i2;
+                if (fast) { *q0 = x0; *q1 = x1; *q2 = x2; }
+                else { store4_sc1(q0, x0); store4_sc1(q1, x1); store4_sc1(q2, x2); }
+            }
+            float* dgh = p_dghw + rix * ldg + ht * 48 + gn_l * 3;      // the row-major copy the weight-gradient GEMM reads
+            dgh[0] = dr; dgh[1] = du; dgh[2] = dn * r_;
             if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
             else carry_reg = dH * u;
-            float* dgi = p_dgi + rix * a.ldg + ht * 48 + gn * 3;
+            float* dgi = p_dgi + rix * ldg + ht * 48 + gn_l * 3;
             dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
@@ -1385,13 +1463,13 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
       }
     }
     if (gate_thread && p_last >= 0 && a.p_end - 1 >= p_last) {      // a later launch over earlier steps continues from memory
-        if constexpr (!PIPE) J.carry[(size_t)(tm.slot * RB + team * 16 + gr) * D + j] = carry_reg;
+        if constexpr (!PIPE) p_carry[(size_t)(tm.slot * RB + team * 16 + gr) * D + j] = carry_reg;
         else
             for (int r = 0; r < tm.nrb; ++r)
-                J.carry[(size_t)((tm.slot + r * tm.cpj) * RB + team * 16 + gr) * D + j] = r == 0 ? carry_r0 : (r == 1 ? carry_r1 : (r == 2 ? carry_r2 : carry_r3));
+                p_carry[(size_t)((tm.slot + r * tm.cpj) * RB + team * 16 + gr) * D + j] = r == 0 ? carry_r0 : (r == 1 ? carry_r1 : (r == 2 ? carry_r2 : carry_r3));
     }
     if constexpr (DIAG) {
-        if (tt == 0 && a.stamps) {
+        if (tt == 0 && a.stamps && ((a.ablate & 256) ? T == 2 : T == 4)) {      // ablate bit 256: the T = 2 launches instead
             for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + 16 + i, ph[i]);
             atomicAdd(a.stamps + 16 + 8, (unsigned long long)(a.p_end - a.p_begin));
             atomicAdd(a.stamps + 16 + 10, 1ULL);
@@ -1498,9 +1576,14 @@ static hipError_t fill_sentinel2d(hipStream_t st, float* base, size_t rows, size
 
 // sentinel-fill the exchanged buffer of every job and zero the sync words; jobs that tile whole rows side
 // by side (the two encoder directions) are covered by ONE linear fill
-static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd)
+static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd, bool team)
 {
     const size_t rows = (size_t)a.S * a.B, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
+    if (team) {       // team kernels exchange through the tiled scratch buffer: one linear fill over every job's part
+        hipLaunchKernelGGL(gru_prepare_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords,
+                           reinterpret_cast<uint4*>(a.xbuf), (size_t)a.njobs * rows * width / 4);
+        return hipGetLastError();
+    }
     float* base0 = fwd ? a.job[0].hs : a.job[0].dgh;
     bool side_by_side = (size_t)a.njobs * width == ld && (((uintptr_t)base0) & 15) == 0 && ((rows * ld) & 3) == 0;
     for (int i = 0; i < a.njobs && side_by_side; ++i)
@@ -1519,9 +1602,12 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd)
 // geometry of the LDS-weight team kernels: C <= 8 chain groups x 32 hidden tiles = at most one 1024-thread workgroup
 // per CU; a chain group = one job and every (C / njobs)-th block of 16 T rows of it.  T = 4 teams (64-row blocks) where
 // that fills the chip, else T = 2 (32-row blocks, K split over 8 waves).  Returns false where neither applies.
-static bool team_geometry(const GruArgs& a, int* T, int* C)
+static bool team_geometry(const GruArgs& a, bool fwd, int* T, int* C)
 {
-    if (a.D != 512 || a.njobs > 2) return false;
+    if (a.D != 512 || a.njobs > 2 || a.p_begin != 0) return false;
+    // the tiled exchange scratch: present, 16-byte aligned, large enough, addressable with 32-bit byte offsets per job
+    const size_t per_job = (size_t)a.S * a.B * a.D * (fwd ? 1 : 3);
+    if (!a.xbuf || (((uintptr_t)a.xbuf) & 15) || a.xbuf_floats < per_job * a.njobs || per_job * 4 >= (1ull << 32)) return false;
     for (int t = 4; t >= 2; t >>= 1) {
         const int rb = 16 * t;
         if (a.B % rb) continue;
@@ -1559,16 +1645,22 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent && a.p_end - a.p_begin > 1) {
-        e = prepare_exchange(st, a, true); if (e != hipSuccess) return e;
         // D = 512: independent 16-row teams sharing one LDS-resident weight slice per CU, the row blocks of a workgroup
         // interleaved item by item (team_geometry picks 4 teams x 4 waves or 2 teams x 8 waves)
         int T = 0, C = 0;
-        if (team_geometry(a, &T, &C) && a.item_pipeline == 2) {
+        bool team = team_geometry(a, true, &T, &C) && a.item_pipeline == 2;
+#ifdef AVAE_DIAG
+        if (a.ablate && ((a.ablate & ~(16 | 128 | 256)) || T != 4)) team = false;
+#else
+        if (a.ablate) team = false;
+#endif
+        e = prepare_exchange(st, a, true, team); if (e != hipSuccess) return e;
+        if (team) {
             const int lds_bytes = (96 * 256 + 48 * 256 + 4 * 256) * 4 + 128;
             const bool pipe = a.njobs * (a.B / (16 * T)) > C;      // several row blocks per workgroup
 #ifdef AVAE_DIAG
             if (a.ablate) {
-                if (!(a.ablate & ~(16 | 128 | 256)) && T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<true, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<true, false, 4>, a, lds_bytes, C);
+                return pipe ? launch_team(st, gru_fwd_team_kernel<true, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<true, false, 4>, a, lds_bytes, C);
             } else
 #endif
             {
@@ -1595,9 +1687,10 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
-        e = prepare_exchange(st, a, false); if (e != hipSuccess) return e;
         int T = 0, C = 0;
-        if (team_geometry(a, &T, &C) && !(a.ablate & ~128) && a.item_pipeline == 2) {
+        const bool team = team_geometry(a, false, &T, &C) && !(a.ablate & ~(16 | 128 | 256)) && a.item_pipeline == 2;
+        e = prepare_exchange(st, a, false, team); if (e != hipSuccess) return e;
+        if (team) {
             const int lds_bytes = (4 * 24 * 256 + 16 * 256 + 64) * 4 + 64;
             const bool pipe = a.njobs * (a.B / (16 * T)) > C;
 #ifdef AVAE_DIAG

@@ -77,6 +77,8 @@ struct GruArgs {
     int* err;             // device error word (set on spin timeout)
     unsigned long long* stamps;   // 32 words of diagnostic phase sums (ablate bit 32) or nullptr
     int item_pipeline;    // 1: use the software-pipelined D = 512 forward kernel where its geometry applies
+    float* xbuf;          // scratch for the team kernels' exchange in MFMA-tile order (see gru.hip "tiled exchange"): at least
+    size_t xbuf_floats;   // njobs*S*B*D floats (forward) / njobs*S*B*3D (backward); nullptr / too small: register-form kernels
     int stagger;          // 1: delay the second half of the grid by ~half a step (co-resident chains de-phased)
     int force_slow;       // 1: never use the same-XCD L2 fast path
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync

@@ -121,6 +121,7 @@ struct Ws {
     // backward
     float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
+    float* xbuf; size_t xbuf_floats;      // exchange scratch of the GRU team kernels (GruArgs::xbuf)
 };
 
 struct Bump {
@@ -157,6 +158,12 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.d_hd[i] = b.take<float>(rt * D);
         w.d_sv[i] = train ? b.take<float>(rt * 4 * D) : nullptr;
         w.d_hp[i] = train ? b.take<float>(rt * D) : nullptr;
+    }
+    {   // every GRU launch exchanges through the same scratch: the largest launch is both encoder directions (forward:
+        // D floats per row and step, backward: 3D) or one decoder layer
+        const size_t rows = std::max<size_t>(2 * rs, rt);
+        w.xbuf_floats = rows * D * (train ? 3 : 1);
+        w.xbuf = b.take<float>(w.xbuf_floats);
     }
     w.hpick = b.take<float>((size_t)B * 2 * D);
     w.mu = b.take<float>((size_t)B * R); w.lv = b.take<float>((size_t)B * R); w.z = b.take<float>((size_t)B * R);
@@ -358,7 +365,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.gi = w.e_gi[i] + d * 3 * D;
@@ -401,7 +408,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.gi = w.d_gi[i]; j.R = h->P + p.R; j.bR = h->P + p.bR;
         j.h0 = state_in + state_stride * i;
@@ -496,7 +503,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
@@ -544,7 +551,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;

@@ -9,8 +9,7 @@ m.step = 20000
 names = ['Aload+poll', 'mfma', 'barrier2', 'gates+store', 'turn-wait', 'loop', 'barrier1', 'write+prefetch']
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else '256,1024').split(',')]:
   ids = torch.as_tensor(synth.batch(B, 64, 8192, seed=0)).cuda()
-  for turn in (0, 2):
-    m.set_option('gru_turn', turn)
+  for turn in (0,):
     for ab in (128, 128 | 16):
       for i in range(2): m.encode(ids)
       m.set_option('gru_ablate', ab)
