@@ -24,6 +24,7 @@
 // that XCD's L2 is the coherence point and plain stores suffice (detected at run time with the
 // placement-independent protocol; speed only).  Every spin is bounded; on time-out the error word
 // is set and every wait falls through, so the grid always drains.
+#include <algorithm>
 #include "kernels.h"
 #include <type_traits>
 
@@ -45,7 +46,22 @@ __device__ __forceinline__ int pos_map(int p, int len, int reverse) { return (re
 // sigmoid / tanh on v_exp_f32 + v_rcp_f32 (each <= 1 ulp): absolute error ~1e-7, far inside the
 // fp32 parity tolerances, at a fraction of the libm cost that sat on the per-step critical path
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
+__device__ __forceinline__ float tanhf_(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
+// One cell update, shared by every forward kernel form.  Which multiply-adds are fused is written out: left to the
+// compiler's contraction the choice followed the surrounding code, and two forms of the same step (the team kernels and
+// the one-launch-per-step kernels the tests compare them with) differed in the last bit.
+struct GruCellOut { float r, u, n, h; };
+__device__ __forceinline__ GruCellOut gru_cell(float gi_r, float gi_u, float gi_n, float gh_r, float gh_u, float gh_n, float hprev)
+{
+    GruCellOut c;
+    c.r = sigmoidf_(gi_r + gh_r);
+    c.u = sigmoidf_(gi_u + gh_u);
+    c.n = tanhf_(__builtin_fmaf(c.r, gh_n, gi_n));
+    float t = (1.f - c.u) * c.n;
+    asm volatile("" : "+v"(t));                   // a product of its own, not a candidate for fusion with the sum below
+    c.h = __builtin_fmaf(c.u, hprev, t);
+    return c;
+}
 
 // k offset (inside one wave's contiguous K range) of MFMA step ks for lane quarter kh
 template <int NKS>
@@ -62,6 +78,28 @@ __device__ __forceinline__ int kperm(int ks, int kh)
 __device__ __forceinline__ u32x4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off)
 {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);     // aux 16 = sc1
+}
+// Buffer forms of the gate-phase accesses: 32-bit byte offsets against a wave-uniform descriptor.  On the texture
+// addresser a buffer instruction costs about half of the global (64-bit address per lane) form of the same access
+// (scripts/micro/ta_cost.hip: x4 store of 4 rows x 256 B 43 vs 83 cycles, dword store 31 vs 63).
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0)); }
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)off, 0, 0); }
+__device__ __forceinline__ void bstore1_sc1(float v, __amdgpu_buffer_rsrc_t rs, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)off, 0, 16); }
+__device__ __forceinline__ void bstore3(float x, float y, float z, __amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    const u32x3 v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z)};
+    __builtin_amdgcn_raw_buffer_store_b96(v, rs, (int)off, 0, 0);
+}
+__device__ __forceinline__ void bstore4(float x, float y, float z, float w, __amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    const u32x4 v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 0);
 }
 __device__ __forceinline__ unsigned load4_sc1(const float* p)
 {
@@ -440,10 +478,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                     gh[gate] = bR[gate] + ((part[buf][c][0][gate][pidx] + part[buf][c][1][gate][pidx]) +
                                            (part[buf][c][2][gate][pidx] + part[buf][c][3][gate][pidx]));
                 const float hprev = hps[buf][c][gr][gn];
-                float r, u, nn;
-                if (ab & 8) { r = 0.5f + 0.1f * (gi[c][0] + gh[0]); u = 0.5f + 0.1f * (gi[c][1] + gh[1]); nn = 0.1f * (gi[c][2] + r * gh[2]); }
-                else { r = sigmoidf_(gi[c][0] + gh[0]); u = sigmoidf_(gi[c][1] + gh[1]); nn = tanhf_(gi[c][2] + r * gh[2]); }
-                const float hnew = (1.f - u) * nn + u * hprev;
+                float r, u, nn, hnew;
+                if (ab & 8) { r = 0.5f + 0.1f * (gi[c][0] + gh[0]); u = 0.5f + 0.1f * (gi[c][1] + gh[1]); nn = 0.1f * (gi[c][2] + r * gh[2]); hnew = (1.f - u) * nn + u * hprev; }
+                else { const GruCellOut cell = gru_cell(gi[c][0], gi[c][1], gi[c][2], gh[0], gh[1], gh[2], hprev); r = cell.r; u = cell.u; nn = cell.n; hnew = cell.h; }
                 // (6) exchanged store first
                 float* hdst = J.hs + ((size_t)gpos[c] * B + row) * a.ldh + j;
                 if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
@@ -629,8 +666,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
             for (int gate = 0; gate < 3; ++gate)
                 gh[gate] = bR[gate] + ((part[buf][0][gate][pidx] + part[buf][1][gate][pidx]) + (part[buf][2][gate][pidx] + part[buf][3][gate][pidx]));
             const float hprev = hps[buf][gr][gn];
-            const float r = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r * gh[2]);
-            const float hnew = (1.f - u) * nn + u * hprev;
+            const GruCellOut cell = gru_cell(gi0, gi1, gi2, gh[0], gh[1], gh[2], hprev);
+            const float r = cell.r, u = cell.u, nn = cell.n, hnew = cell.h;
             const size_t rix = (size_t)gpos * B + grow;
             float* hdst = J.hs + rix * a.ldh + j;
             if (fast) *hdst = not_sentinel(hnew); else store4_sc1(hdst, not_sentinel(hnew));
@@ -718,15 +755,14 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     unsigned* sync = reinterpret_cast<unsigned*>(hps + T * 256);      // [team T] barrier counters, [team T] exchange-ready epochs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // wave -> (team, K-split index).  Waves w and w + 4 share a SIMD, and a team's K-split partners meet at a barrier
-    // every step: the FEWER SIMDs they sit on, the less arbitration skew that barrier pays (measured, gpurun_out/ab5.log,
-    // B = 256: partners on four SIMDs 7.76 ms of GRU per step, confined 7.38).  T = 4, one row block: each team on ONE
-    // SIMD (four independent chains, one per matrix pipe); several row blocks (PIPE): on TWO SIMDs, two teams per pair,
-    // so that a pipe always has a second team's MFMAs (B = 1024: 78.4 vs 80.3 ms per step); T = 2: each team on two SIMDs.
+    // wave -> (team, K-split index).  Waves w and w + 4 share a SIMD; a team's K-split partners meet at a barrier every
+    // step.  Which SIMDs a team sits on is a 1-3 % effect since the operand loads stopped saturating the texture
+    // addresser; the mapping per form is the best of {one SIMD, a SIMD pair, all four} measured in-process
+    // (gpurun_out/ab16.log, scripts/ab_classes.py).
     int team, wk;
-    if (T == 4 && !PIPE)     { team = wave & 3; wk = wave >> 2; }
-    else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }
-    else                     { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }
+    if (T == 4 && PIPE)      { team = wave & 3; wk = wave >> 2; }                                              // one SIMD
+    else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }    // a SIMD pair
+    else                     { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
     const int n = lane & 15, kh = lane >> 4;
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
@@ -754,6 +790,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     float* __restrict__ p_hsw = J.hs;
     float* const xh = a.xbuf + (size_t)tm.jb * a.S * B * D;          // this job's exchange buffer (tiled, sentinel-filled)
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(xh), rs_h0 = make_rsrc(J.h0 ? J.h0 : xh);
+    const __amdgpu_buffer_rsrc_t rs_gi = make_rsrc(p_gi), rs_hsw = make_rsrc(p_hsw);
+    const __amdgpu_buffer_rsrc_t rs_svw = make_rsrc(p_svw ? p_svw : p_hsw), rs_hpw = make_rsrc(p_hpw ? p_hpw : p_hsw);
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (KS * 3 * 256);
     float* thps = hps + team * 256;
@@ -809,9 +847,12 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
-        const float* gp = p_gi + ((size_t)gpos * B + grow) * a.ldg + ht * 48 + gn * 3;
+        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)grow;      // (byte offsets below 2^32: team_geometry checks)
         float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f;
-        if (gate_thread) { gi0 = gp[0]; gi1 = gp[1]; gi2 = gp[2]; }
+        if (gate_thread) {
+            const u32x3 g3 = __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)((rix * (unsigned)a.ldg + ht * 48 + gn * 3) * 4u), 0, 0);
+            gi0 = __uint_as_float(g3.x); gi1 = __uint_as_float(g3.y); gi2 = __uint_as_float(g3.z);
+        }
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
         const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p + 1;
         int len2 = len_a, len2g = len_g;
@@ -907,14 +948,13 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 gh[gate] = bR[gate] + ((s4[0] + s4[1]) + (s4[2] + s4[3]));
             }
             const float hprev = thps[gr * 16 + gn];
-            const float r_ = sigmoidf_(gi0 + gh[0]), u = sigmoidf_(gi1 + gh[1]), nn = tanhf_(gi2 + r_ * gh[2]);
-            const float hnew = (1.f - u) * nn + u * hprev;
-            const size_t rix = (size_t)gpos * B + grow;
-            float* xdst = xh + xch_index(gpos, grow, j, B, D);      // exchanged store first
-            if (fast) *xdst = not_sentinel(hnew); else store4_sc1(xdst, not_sentinel(hnew));
-            p_hsw[rix * a.ldh + j] = hnew;                          // the row-major copy the GEMMs and the next layer read
-            if (p_svw) *reinterpret_cast<float4*>(p_svw + (rix * HT + ht) * 64 + gn * 4) = make_float4(r_, u, nn, gh[2]);
-            if (p_hpw) p_hpw[rix * D + j] = hprev;
+            const GruCellOut cell = gru_cell(gi0, gi1, gi2, gh[0], gh[1], gh[2], hprev);
+            const float r_ = cell.r, u = cell.u, nn = cell.n, hnew = cell.h;
+            const unsigned xo = xch_index(gpos, grow, j, B, D) * 4u;      // exchanged store first
+            if (fast) bstore1(not_sentinel(hnew), rs_hs, xo); else bstore1_sc1(not_sentinel(hnew), rs_hs, xo);
+            bstore1(hnew, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);       // the row-major copy the GEMMs and the next layer read
+            if (p_svw) bstore4(r_, u, nn, gh[2], rs_svw, ((rix * HT + ht) * 64 + gn * 4) * 4u);
+            if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
         }
         len_a = len2; len_g = len2g;
         TSTAMP(3);
@@ -1217,15 +1257,15 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     unsigned* sync = reinterpret_cast<unsigned*>(red + 64); // [team 4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // wave -> (team, K-split index).  Waves w and w + 4 share a SIMD, and a team's K-split partners meet at a barrier
-    // every step: the FEWER SIMDs they sit on, the less arbitration skew that barrier pays (measured, gpurun_out/ab5.log,
-    // B = 256: partners on four SIMDs 7.76 ms of GRU per step, confined 7.38).  T = 4, one row block: each team on ONE
-    // SIMD (four independent chains, one per matrix pipe); several row blocks (PIPE): on TWO SIMDs, two teams per pair,
-    // so that a pipe always has a second team's MFMAs (B = 1024: 78.4 vs 80.3 ms per step); T = 2: each team on two SIMDs.
+    // wave -> (team, K-split index).  Waves w and w + 4 share a SIMD; a team's K-split partners meet at a barrier every
+    // step.  Which SIMDs a team sits on is a 1-3 % effect since the operand loads stopped saturating the texture
+    // addresser; the mapping per form is the best of {one SIMD, a SIMD pair, all four} measured in-process
+    // (gpurun_out/ab16.log, scripts/ab_classes.py).
     int team, wk;
-    if (T == 4 && !PIPE)     { team = wave & 3; wk = wave >> 2; }
-    else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }
-    else                     { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }
+    if (T == 4 && PIPE)      { team = wave & 3; wk = wave >> 2; }                                              // one SIMD
+    else if (T == 4)         { team = wave >> 2; wk = wave & 3; }                                              // all four SIMDs
+    else if (PIPE)           { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
+    else                     { team = wave >> 3; wk = wave & 7; }                                              // all four SIMDs
     const int n = lane & 15, kh = lane >> 4;
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
@@ -1235,10 +1275,13 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
     for (int blk = wave; blk < 96; blk += 16) {
         const int wq = blk / KB4, ks4 = blk % KB4;
-        const float* rp = J.R + (size_t)(wq * WKB + 16 * ks4 + 4 * kh) * D + ht * 16 + n;
-        *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[D], rp[2 * D], rp[3 * D]);
+        // the exchanged operand is in gate-major order inside a producer's 48 columns (kx = tile*48 + gate*16 + unit, so
+        // that a producer wave's store of one gate covers whole 16-byte groups); R' rows are in unit-major order
+        const int kx = wq * WKB + 16 * ks4 + 4 * kh, rem = kx % 48;
+        const float* rp = J.R + (size_t)((kx - rem) + (rem & 15) * 3 + (rem >> 4)) * D + ht * 16 + n;
+        *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[3 * D], rp[6 * D], rp[9 * D]);
     }
-    if (tid < T) sync[tid] = 0u;
+    if (tid < 2 * T) sync[tid] = 0u;
     if (tid < 64) red[tid] = 0.f;
     const int tt = wk * 64 + lane, gn = tt & 15, gr = (tt >> 4) & 15;
     const bool gate_thread = tt < 256;                        // the team's first 256 threads own one (row, unit) each
@@ -1255,6 +1298,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     }
     float* tpart = part + team * (KS * 256);
     unsigned* tsync = sync + team;
+    unsigned* ready = sync + T + team;                        // exchange-ready epoch (one polling wave per team, see the forward)
     unsigned epoch = 0;
     {
         const int tq = __builtin_amdgcn_readfirstlane(team);      // one arbitration order on all four SIMDs (see the forward)
@@ -1288,6 +1332,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     float carry_r0 = 0.f, carry_r1 = 0.f, carry_r2 = 0.f, carry_r3 = 0.f;      // PIPE: the same, per row block
     u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(xg);
+    const __amdgpu_buffer_rsrc_t rs_sv = make_rsrc(p_sv), rs_hp = make_rsrc(p_hp), rs_do = make_rsrc(p_do ? p_do : p_hp);
+    const __amdgpu_buffer_rsrc_t rs_dgi = make_rsrc(p_dgi), rs_dghw = make_rsrc(p_dghw);
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
         return xch_lane_offset(pos_map(p + 1, len_a, j_rev), row0, wk * (WKB / 4), n, kh, B, 3 * D);
     };
@@ -1339,12 +1385,12 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         BSTAMP(7);
         // (1) exchange-independent loads of the gate phase
         const int gpos = pos_map(p < 0 ? 0 : p, len_g, j_rev);
-        const size_t rix = (size_t)gpos * B + grow;
+        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)grow;      // (byte offsets below 2^32: team_geometry checks)
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
         if (p >= 0 && gate_thread) {
-            sv = *reinterpret_cast<const float4*>(p_sv + (rix * HT + ht) * 64 + gn_l * 4);
-            s_hp = p_hp[rix * D + j_l];
-            s_do = p_do ? p_do[rix * ldh + j_l] : 0.f;
+            sv = bload4(rs_sv, ((rix * HT + ht) * 64 + gn_l * 4) * 4u);
+            s_hp = bload1(rs_hp, (rix * D + j_l) * 4u);
+            s_do = p_do ? bload1(rs_do, (rix * (unsigned)ldh + j_l) * 4u) : 0.f;
         }
         // dH_{p+1} u_{p+1} of this (row, unit): written by this same thread one step ago
         // (PIPE: fetched here, ahead of the next item's operand loads -- memory returns in order, so a load issued
@@ -1394,11 +1440,22 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
                 const int len_p = PIPE ? (j_rev ? p_lens[row0 + 15] : 0) : len_p0;      // (one row block: fetched once, before the loop)
                 const float* pp = xg + xch_index(pos_map(p + 1, len_p, j_rev), row0 + 15, (ln_l & 31) * 48 + 47, B, 3 * D);
-                while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(p_err)) { }
+                for (;;) {
+                    unsigned v = 0u;
+                    if (ln_l < 32) v = load4_sc1(pp);              // 32 cache lines per poll: half the wave stays out of it
+                    if (!__any(v == kSentinel) || sg.expired(p_err)) break;
+                }
             };
             SpinGuard sg;
             if constexpr (!PIPE) {
-                if (poll) probe(sg);
+                if (poll) {     // ONE wave per team polls (a poll costs ~180 texture-addresser cycles) and releases its partners through LDS
+                    if (wk == 0) {
+                        probe(sg);
+                        if (lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
+                    }
+                }
                 head(voff);
             }
             BSTAMP(1);
@@ -1442,20 +1499,16 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             const float du = dH * (s_hp - nn) * u * (1.f - u);
             const float dr = dn * sv.w * r_ * (1.f - r_);
             const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
-            {   // exchanged stores first (tiled buffer: three dwords, possibly in two 16-byte chunks)
-                const int k0 = ht * 48 + gn_l * 3;                   // k0 % 4 == (gn * 3) % 4; the next k is 1 float on, or 61 across a chunk
-                const unsigned i0 = xch_index(gpos, grow, k0, B, 3 * D);
-                const unsigned i1 = i0 + (((k0 & 3) == 3) ? 61u : 1u), i2 = i1 + ((((k0 + 1) & 3) == 3) ? 61u : 1u);
-                float* q0 = xg + i0; float* q1 = xg + i1; float* q2 = xg + i2;
-                if (fast) { *q0 = x0; *q1 = x1; *q2 = x2; }
-                else { store4_sc1(q0, x0); store4_sc1(q1, x1); store4_sc1(q2, x2); }
+            {   // exchanged stores first (tiled buffer, gate-major: gate g of this unit sits 4 chunks = 1 KB after gate g - 1)
+                const unsigned o0 = xch_index(gpos, grow, ht * 48 + gn_l, B, 3 * D) * 4u;
+                if (fast) { bstore1(x0, rs_dgh, o0); bstore1(x1, rs_dgh, o0 + 1024u); bstore1(x2, rs_dgh, o0 + 2048u); }
+                else { bstore1_sc1(x0, rs_dgh, o0); bstore1_sc1(x1, rs_dgh, o0 + 1024u); bstore1_sc1(x2, rs_dgh, o0 + 2048u); }
             }
-            float* dgh = p_dghw + rix * ldg + ht * 48 + gn_l * 3;      // the row-major copy the weight-gradient GEMM reads
-            dgh[0] = dr; dgh[1] = du; dgh[2] = dn * r_;
+            const unsigned orow = (rix * (unsigned)ldg + ht * 48 + gn_l * 3) * 4u;
+            bstore3(dr, du, dn * r_, rs_dghw, orow);                 // the row-major copy the weight-gradient GEMM reads
             if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
             else carry_reg = dH * u;
-            float* dgi = p_dgi + rix * ldg + ht * 48 + gn_l * 3;
-            dgi[0] = dr; dgi[1] = du; dgi[2] = dn;
+            bstore3(dr, du, dn, rs_dgi, orow);
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
         len_a = len2; len_g = len2g;
@@ -1608,6 +1661,9 @@ static bool team_geometry(const GruArgs& a, bool fwd, int* T, int* C)
     // the tiled exchange scratch: present, 16-byte aligned, large enough, addressable with 32-bit byte offsets per job
     const size_t per_job = (size_t)a.S * a.B * a.D * (fwd ? 1 : 3);
     if (!a.xbuf || (((uintptr_t)a.xbuf) & 15) || a.xbuf_floats < per_job * a.njobs || per_job * 4 >= (1ull << 32)) return false;
+    // (the gate phase addresses gi / hs / saved gates / dgi / dgh with 32-bit byte offsets as well)
+    const size_t widest = std::max<size_t>((size_t)std::max(a.ldg, a.ldh), (size_t)4 * a.D);
+    if ((size_t)a.S * a.B * widest * 4 >= (1ull << 32)) return false;
     for (int t = 4; t >= 2; t >>= 1) {
         const int rb = 16 * t;
         if (a.B % rb) continue;

@@ -10,7 +10,7 @@ names = ['top-loads', 'probe+head', 'stream+mfma', 'barrier1', 'write', 'barrier
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else '256').split(',')]:
     ids = torch.as_tensor(synth.batch(B, 64, 8192, seed=0)).cuda()
     for i in range(2): m.train_step(ids, ids, seed=i)
-    for sel in (16, 16 | 8192, 256 | 16, 256 | 16 | 8192):                      # 0: the T = 4 launches (encoder at B = 256), 256: the T = 2 launches (decoder)
+    for sel in (0, 16, 256, 256 | 16):                      # 0: the T = 4 launches (encoder at B = 256), 256: the T = 2 launches (decoder)
         m.set_option('gru_ablate', 128 | sel)
         out = (C.c_uint64 * 32)()
         m._l.avae_debug_stamps(m._h, out)
