@@ -260,18 +260,23 @@ __device__ __forceinline__ void load_frag_scalar(float* dst, const float* base, 
 __device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, int ht, int HT, int* err, int force_slow)
 {
     __shared__ int s_fast;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {          // the first wave: lane 0 publishes and waits, then lane i reads id i (one round trip, not HT)
         const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
-        __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        SpinGuard sg; bool ok = true;
-        while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HT)
-            if (sg.expired(err)) { ok = false; break; }
-        bool same = ok && !force_slow;
-        for (int i = 0; i < HT && same; ++i)
-            same = __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my + 1u;
-        s_fast = same ? 1 : 0;
+        bool ok = true;
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            SpinGuard sg;
+            while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HT)
+                if (sg.expired(err)) { ok = false; break; }
+        }
+        ok = __all(ok);
+        bool same = true;
+        for (int i = threadIdx.x; i < HT; i += 64)
+            same = same && __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my + 1u;
+        same = __all(same) && ok && !force_slow;
+        if (threadIdx.x == 0) s_fast = same ? 1 : 0;
     }
     __syncthreads();
     return s_fast != 0;
@@ -897,17 +902,29 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         f32x4 acc[3];
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            f32x4 b[3];
+        {   // B fragments one q ahead of their MFMAs (see the backward)
+            f32x4 bn[3];
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
-                b[gate] = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 3 + gate) * NQ + q) * 256 + lane * 4);
+                bn[gate] = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 3 + gate) * NQ + 0) * 256 + lane * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)            // gates interleaved: consecutive MFMAs hit different accumulators
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 b[3];
 #pragma unroll
-                for (int gate = 0; gate < 3; ++gate)
-                    acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ra[q][e]), b[gate][e], acc[gate], 0, 0, 0);
+                for (int gate = 0; gate < 3; ++gate) b[gate] = bn[gate];
+                if (q + 1 < NQ) {
+#pragma unroll
+                    for (int gate = 0; gate < 3; ++gate)
+                        bn[gate] = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * 3 + gate) * NQ + q + 1) * 256 + lane * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise sinks the reads back to their use)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)            // gates interleaved: consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int gate = 0; gate < 3; ++gate)
+                        acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ra[q][e]), b[gate][e], acc[gate], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         TSTAMP(1);
         // every wave of the team has finished READING the previous item's partial sums (second team barrier
@@ -1412,6 +1429,12 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             f32x4 acc[2];
             auto pass = [&]() __attribute__((always_inline)) -> bool {
                 unsigned mx = 0u;
+                // B fragments one step ahead of their MFMAs: read right before use, every ds_read_b128 was followed by a
+                // full lgkmcnt(0) wait and a lone wave's matrix pipe idled ~100 cycles per four MFMAs
+                auto ldsB = [&](int st_, int q_) __attribute__((always_inline)) {
+                    return *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * KB4 + st_ * 6 + q_) * 64 + lane) * 4);
+                };
+                f32x4 bq = ldsB(0, 0);
 #pragma unroll
                 for (int st = 0; st < NH; ++st) {
                     const int issued = (NB + st < NH) ? NB + st : NH;                       // pieces issued so far
@@ -1426,10 +1449,13 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                     asm volatile("" : "+v"(mx));
 #pragma unroll
                     for (int q = 0; q < PQ; ++q) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * KB4 + st * 6 + q) * 64 + lane) * 4);
+                        const f32x4 b = bq;
+                        if (q + 1 < PQ) bq = ldsB(st, q + 1); else if (st + 1 < NH) bq = ldsB(st + 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise sinks the read back to its use)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][q][e]), b[e], acc[e & 1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if (st + NB < NH) issue_piece(st + NB, hv[st % NB], voff);
                 }

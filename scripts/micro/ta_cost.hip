@@ -56,8 +56,35 @@ __global__ __launch_bounds__(1024) void k(float* base, int pat, int width, int i
     }
     if (acc == 123.456f) sink[0] = acc;
 }
+// does a clock read right after vector stores report the time of the read, or does it wait behind them?
+__global__ __launch_bounds__(1024) void clock_after_store(float* base, int nstores, unsigned long long* out)
+{
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* region = base + ((size_t)blockIdx.x * 16 + w) * 65536;
+    unsigned long long d01 = 0, d12 = 0, d23 = 0;
+    for (int it = 0; it < 200; ++it) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < nstores; ++i) __hip_atomic_store(region + ((it & 7) * 8 + i) * 256 + (l & 15) * 3 + (l >> 4) * 64, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_branch 1f\n1:" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+        d01 += t1 - t0; d12 += t2 - t1; d23 += t3 - t2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = d01; out[1] = d12; out[2] = d23; }
+}
 int main()
 {
+    {
+        float* b2; CK(hipMalloc(&b2, (size_t)256 * 16 * 65536 * 4)); unsigned long long* o; CK(hipMalloc(&o, 64)); unsigned long long h[3];
+        for (int ns : {0, 2, 6}) {
+            hipLaunchKernelGGL(clock_after_store, dim3(256), dim3(1024), 0, 0, b2, ns, o); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h, o, 24, hipMemcpyDeviceToHost));
+            printf("clock reads around %d stores (16 waves/CU): stores %.3f us, back-to-back read %.3f us, read after a branch %.3f us\n", ns, h[0] / 200.0 * 0.01, h[1] / 200.0 * 0.01, h[2] / 200.0 * 0.01);
+        }
+        CK(hipFree(b2)); CK(hipFree(o));
+    }
     float* buf; CK(hipMalloc(&buf, (size_t)256 * 16 * (1u << 18) + 4096)); CK(hipMemset(buf, 0, (size_t)256 * 16 * (1u << 18)));
     float* sink; CK(hipMalloc(&sink, 64));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
