@@ -32,6 +32,47 @@ namespace avae {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> two bf16 (round to nearest even, v_cvt_pk_bf16_f32), `lo` in the low half
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// 16-bit exchange (bf16 mode, backward team kernels): the exchanged operand itself is stored as bf16, eight k per 16-byte
+// chunk -- element (pos, row, k) at halfword
+//     X[(((pos * B/16 + row/16) * K/8 + k/8) * 16 + row%16) * 8 + k%8]
+// -- so one load instruction of a wave still reads 1 KB of contiguous memory and IS the v_mfma_f32_16x16x32_bf16 A operand
+// (half the bytes through the texture addresser, no conversion, the whole K range of a wave in flight at once).  "Not
+// yet written" is the halfword 0xFFFF (the launcher's fill); a stored value with that pattern (a NaN) becomes 0x7FC0.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned xch16_index(int pos, int row, int k, int B, int K)
+{
+    return ((((unsigned)pos * (unsigned)(B >> 4) + (unsigned)(row >> 4)) * (unsigned)(K >> 3) + (unsigned)(k >> 3)) * 16u + (unsigned)(row & 15)) * 8u + (unsigned)(k & 7);
+}
+__device__ __forceinline__ unsigned short bf16_not_sentinel(float v)
+{
+    const unsigned short h = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+    return h == 0xffffu ? (unsigned short)0x7fc0u : h;
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ bool any_half_sentinel(unsigned mx) { return (mx & 0xffffu) == 0xffffu || (mx >> 16) == 0xffffu; }
+// bf16-operand mode in the register-form kernels: the operand keeps its fp32 register but carries a bf16 value (products of
+// two such values are exact in fp32, so these kernels and the team kernels' bf16 MFMA differ only in summation order)
+__device__ __forceinline__ float opnd(float x, bool bf) { return bf ? __uint_as_float(pack_bf16(0.f, x)) : x; }
+// eight floats (two 16-byte pieces of an MFMA A fragment) -> one v_mfma_f32_16x16x32_bf16 operand.  Which k a slot
+// stands for is the caller's business: the B operand in LDS is packed with the same slot order.
+__device__ __forceinline__ bf16x8 pack_bf16x8(const u32x4& p0, const u32x4& p1)
+{
+    const u32x4 v = {pack_bf16(__uint_as_float(p0.x), __uint_as_float(p0.y)), pack_bf16(__uint_as_float(p0.z), __uint_as_float(p0.w)),
+                     pack_bf16(__uint_as_float(p1.x), __uint_as_float(p1.y)), pack_bf16(__uint_as_float(p1.z), __uint_as_float(p1.w))};
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 constexpr unsigned kSentinel = 0xFFFFFFFFu;
 
@@ -332,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
     const bool one_sc = row_end - row_beg <= 32;               // single super-chunk: lengths stay in registers
 
     // weights -> registers, MFMA B-operand order: B[k][n] = R'[ht*48 + gate*16 + n][k]
+    const bool bf = a.bf16 != 0;                                // bf16-operand mode: both operands of h R' carry bf16 values
     float w[3][KS];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
@@ -346,6 +388,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) w[gate][ks] = rp[kperm<KS>(ks, kh)];
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[gate][ks] = opnd(w[gate][ks], bf);
     }
     const int gn = tid & 15, gr = tid >> 4;        // gate-phase item: unit gn, row gr (+16 per chunk)
     const int j = ht * 16 + gn;
@@ -447,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_kernel(GruArgs a)
                     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                         for (int gate = 0; gate < 3; ++gate)
-                            acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(aval(ks), w[gate][ks], acc[gate], 0, 0, 0);
+                            acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(aval(ks), bf), w[gate][ks], acc[gate], 0, 0, 0);
                 }
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate)
@@ -562,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
     const int B = a.B;
     const int row_beg = g * 32;
 
+    const bool bf = a.bf16 != 0;                                // bf16-operand mode (see gru_fwd_kernel)
     float w[3][KS];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
@@ -569,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
             float4 v = *reinterpret_cast<const float4*>(rp + 16 * q + 4 * kh);
-            w[gate][4 * q + 0] = v.x; w[gate][4 * q + 1] = v.y; w[gate][4 * q + 2] = v.z; w[gate][4 * q + 3] = v.w;
+            w[gate][4 * q + 0] = opnd(v.x, bf); w[gate][4 * q + 1] = opnd(v.y, bf); w[gate][4 * q + 2] = opnd(v.z, bf); w[gate][4 * q + 3] = opnd(v.w, bf);
         }
     }
     const int gn = tid & 15, gr = tid >> 4;
@@ -653,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_item_kernel(GruArgs a)
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
-                acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(cur[ks >> 2][ks & 3]), w[gate][ks], acc[gate], 0, 0, 0);
+                acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(__uint_as_float(cur[ks >> 2][ks & 3]), bf), w[gate][ks], acc[gate], 0, 0, 0);
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
             *reinterpret_cast<f32x4*>(&part[buf][wave][gate][lane * 4]) = acc[gate];
@@ -748,7 +793,11 @@ __device__ __forceinline__ TeamMap team_map(const GruArgs& a, int rows_per_block
 // T teams of KS = 16 / T waves: T = 4 (64 rows per workgroup, K split over 4 waves) where a job fills the chip with 64-row
 // blocks, T = 2 (32 rows, K split over 8 waves: half the MFMAs and half the operand bytes per wave and step on the
 // latency chain) where it does not, e.g. one decoder layer at B = 256.
-template <bool DIAG, bool PIPE, int T>
+// BF (bf16-operand mode, compute_dtype 1): the recurrent product h R' rounds both operands to bf16 like every other
+// contraction of that mode -- weights packed as bf16 in LDS (48 KB), the fp32 A fragment converted in registers,
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (12 MFMAs of 16 cycles per wave and item instead of 96 of 32).  The
+// exchange, the state h, the gate math and everything saved stay fp32.
+template <bool DIAG, bool PIPE, int T, bool BF = false>
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
     const int ab = DIAG ? a.ablate : 0;                     // timing experiments / stamps: diagnostic instantiation only
@@ -775,6 +824,15 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int B = a.B;
 
     // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
+    if constexpr (BF) {   // block (wk', gate, q2): the lane's 8 bf16 = the k of fp32 blocks 2 q2 and 2 q2 + 1, 16 bytes per lane
+        for (int blk = wave; blk < 48; blk += 16) {
+            const int wq = blk / (3 * (NQ / 2)), gate = (blk / (NQ / 2)) % 3, q2 = blk % (NQ / 2);
+            const float* rp = J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 32 * q2 + 4 * kh;
+            const float4 v0 = *reinterpret_cast<const float4*>(rp), v1 = *reinterpret_cast<const float4*>(rp + 16);
+            const u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
+            *reinterpret_cast<u32x4*>(Wl + (size_t)blk * 256 + lane * 4) = pk;
+        }
+    } else
     for (int blk = wave; blk < 96; blk += 16) {
         const int wq = blk / (3 * NQ), gate = (blk / NQ) % 3, q = blk % NQ;
         const float4 v = *reinterpret_cast<const float4*>(J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 16 * q + 4 * kh);
@@ -902,6 +960,17 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         f32x4 acc[3];
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) acc[gate] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
+#pragma unroll
+            for (int q2 = 0; q2 < NQ / 2; ++q2) {
+                const bf16x8 a8 = pack_bf16x8(ra[2 * q2], ra[2 * q2 + 1]);
+#pragma unroll
+                for (int gate = 0; gate < 3; ++gate) {
+                    const bf16x8 b8 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + (size_t)((wk * 3 + gate) * (NQ / 2) + q2) * 256 + lane * 4));
+                    acc[gate] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[gate], 0, 0, 0);
+                }
+            }
+        } else
         {   // B fragments one q ahead of their MFMAs (see the backward)
             f32x4 bn[3];
 #pragma unroll
@@ -1011,10 +1080,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
     const bool one_sc = row_end - row_beg <= 32;
 
     // B operand: B[k = c'][n] = R'[c'][ht*16 + n]
+    const bool bf = a.bf16 != 0;                                // bf16-operand mode (see gru_fwd_kernel)
     float w[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
-        w[ks] = J.R[(size_t)(wave * 12 * KS + kperm<NKS>(ks, kh)) * D + ht * 16 + n];
+        w[ks] = opnd(J.R[(size_t)(wave * 12 * KS + kperm<NKS>(ks, kh)) * D + ht * 16 + n], bf);
 
     const int gn = tid & 15, gr = tid >> 4;
     const int j = ht * 16 + gn;
@@ -1126,7 +1196,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                             asm volatile("" : "+v"(mx));
 #pragma unroll
                             for (int ks = 0; ks < HK; ++ks)
-                                acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][ks >> 2][ks & 3]),
+                                acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(__uint_as_float(hv[st % NB][ks >> 2][ks & 3]), bf),
                                                                                    w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
                             if (hf == NH - 1) {
                                 f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -1172,13 +1242,13 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
                                 if (poll) frag_ensure<PQ>(hv[st % NB], rs_dgh, piece_off(c, hf) + 16 * kh, a.err);
 #pragma unroll
                                 for (int ks = 0; ks < HK; ++ks)
-                                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[st % NB][ks >> 2][ks & 3]),
+                                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(__uint_as_float(hv[st % NB][ks >> 2][ks & 3]), bf),
                                                                                        w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
                             } else {
                                 load_frag_scalar<HK, NKS>(hs_, J.dgh + piece_off(c, 0) / 4, hf * HK, kh, poll, a.err);
 #pragma unroll
                                 for (int ks = 0; ks < HK; ++ks)
-                                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hs_[ks], w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
+                                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(hs_[ks], bf), w[ks + hf * HK], acc[ks & 3], 0, 0, 0);
                             }
                         }
                         if (hf == NH - 1) {
@@ -1259,16 +1329,17 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 // probe of the register-form D = 512 path above, with a ring of NB 24-register pieces (128-register budget at 4 waves
 // per SIMD) whose first NB pieces are in flight before the MFMAs start.  A job with dh0 (decoder layers) gets the
 // tail item p = -1: dh0 = carry + dgh_0 R.  Teams synchronise through monotonic LDS counters, never s_barrier.
-template <int NB, bool PIPE, int T, bool DIAG = false>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves (see the forward)
+template <int NB, bool PIPE, int T, bool DIAG = false, bool BF = false>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves; BF: bf16 operands (see the forward)
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
     // diagnostic phase stamps (DIAG instantiation only): [0] top loads [1] probe + first pieces [2] operand stream + MFMAs
     // [3] barrier 1 [4] partial write + prefetch [5] barrier 2 [6] gate derivatives + stores
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ULL;
 #define BSTAMP(i) do { if constexpr (DIAG) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
-    constexpr int D = 512, HT = 32, PQ = 6, KS = 16 / T, WKB = 3 * D / KS, NH = WKB / 96, KB4 = 96 / KS, RB = 16 * T;
+    // KPL = k values per load instruction (1 KB of the tiled exchange): 16 floats, or 32 bf16 in the 16-bit exchange of BF
+    constexpr int D = 512, HT = 32, PQ = 6, KS = 16 / T, WKB = 3 * D / KS, KPL = BF ? 32 : 16, NH = WKB / (PQ * KPL), KB4 = 96 / KS, RB = 16 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wl = lds;                                        // [wk KS][ks4 KB4][lane 64][4]    96 KB
+    float* Wl = lds;                                        // [wk KS][ks4 KB4][lane 64][4]    96 KB (BF: [wk][WKB/32][lane][8 bf16], 48 KB)
     float* part = Wl + 96 * 256;                            // [team T][wk KS][256]            16 KB
     float* red = part + 16 * 256;                           // [4][16] bias-gradient sums
     unsigned* sync = reinterpret_cast<unsigned*>(red + 64); // [team 4]
@@ -1290,12 +1361,20 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int B = a.B, S = a.S;
 
     // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
+    // the exchanged operand is in gate-major order inside a producer's 48 columns (kx = tile*48 + gate*16 + unit, so
+    // that a producer wave's store of one gate covers whole 16-byte groups); R' rows are in unit-major order
+    auto r_row = [&](int kx) -> const float* { const int rem = kx % 48; return J.R + (size_t)((kx - rem) + (rem & 15) * 3 + (rem >> 4)) * D + ht * 16 + n; };
+    if constexpr (BF) {   // block (wq, kp): lane (n, kh) holds the 8 bf16 R'[wq*WKB + 32 kp + 8 kh + e][ht*16 + n], e = 0..7
+        for (int blk = wave; blk < 48; blk += 16) {
+            const int wq = blk / (KB4 / 2), kp = blk % (KB4 / 2);
+            const float* r0 = r_row(wq * WKB + 32 * kp + 8 * kh);          // (8 consecutive kx stay inside one 16-unit gate group)
+            const u32x4 pk = {pack_bf16(r0[0], r0[3 * D]), pack_bf16(r0[6 * D], r0[9 * D]), pack_bf16(r0[12 * D], r0[15 * D]), pack_bf16(r0[18 * D], r0[21 * D])};
+            *reinterpret_cast<u32x4*>(Wl + (size_t)blk * 256 + lane * 4) = pk;
+        }
+    } else
     for (int blk = wave; blk < 96; blk += 16) {
         const int wq = blk / KB4, ks4 = blk % KB4;
-        // the exchanged operand is in gate-major order inside a producer's 48 columns (kx = tile*48 + gate*16 + unit, so
-        // that a producer wave's store of one gate covers whole 16-byte groups); R' rows are in unit-major order
-        const int kx = wq * WKB + 16 * ks4 + 4 * kh, rem = kx % 48;
-        const float* rp = J.R + (size_t)((kx - rem) + (rem & 15) * 3 + (rem >> 4)) * D + ht * 16 + n;
+        const float* rp = r_row(wq * WKB + 16 * ks4 + 4 * kh);
         *reinterpret_cast<float4*>(Wl + (size_t)blk * 256 + lane * 4) = make_float4(rp[0], rp[3 * D], rp[6 * D], rp[9 * D]);
     }
     if (tid < 2 * T) sync[tid] = 0u;
@@ -1337,7 +1416,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int* p_lens = a.lens;
     int* p_err = a.err;
     const int j_rev = J.reverse, ldg = a.ldg, ldh = a.ldh;
-    float* const xg = a.xbuf + (size_t)tm.jb * S * B * (3 * D);       // this job's exchange buffer (tiled, sentinel-filled)
+    float* const xg = a.xbuf + (size_t)tm.jb * S * B * (3 * D) / (BF ? 2 : 1);       // this job's exchange buffer (tiled, sentinel-filled)
     const unsigned long long pa = (unsigned long long)xg;
     const i32x4 srd = {(int)(unsigned)(pa & 0xffffffffULL), (int)(unsigned)((pa >> 32) & 0xffffULL), -1, 0x00020000};
     float sb_r = 0.f, sb_u = 0.f, sb_n = 0.f, sb_nr = 0.f;
@@ -1352,10 +1431,11 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const __amdgpu_buffer_rsrc_t rs_sv = make_rsrc(p_sv), rs_hp = make_rsrc(p_hp), rs_do = make_rsrc(p_do ? p_do : p_hp);
     const __amdgpu_buffer_rsrc_t rs_dgi = make_rsrc(p_dgi), rs_dghw = make_rsrc(p_dghw);
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
+        if constexpr (BF) return xch_lane_offset(pos_map(p + 1, len_a, j_rev), row0, wk * (WKB / 8), n, kh, B, 3 * D / 2);
         return xch_lane_offset(pos_map(p + 1, len_a, j_rev), row0, wk * (WKB / 4), n, kh, B, 3 * D);
     };
     auto issue_piece = [&](int piece, u32x4 (&dst)[PQ], unsigned vo) __attribute__((always_inline)) {
-        asm_issue6x(dst, vo, srd, 6144 * piece, 6144 * piece + 4096);       // a piece = 96 floats of K = 24 chunks of 256 B
+        asm_issue6x(dst, vo, srd, 6144 * piece, 6144 * piece + 4096);       // a piece = 96 floats (BF: 192 bf16) of K = 24 chunks of 256 B
     };
     // the first NB pieces go in flight BEFORE the item's MFMAs, the rest behind the MFMAs of the piece whose
     // registers they reuse
@@ -1434,7 +1514,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 auto ldsB = [&](int st_, int q_) __attribute__((always_inline)) {
                     return *reinterpret_cast<const f32x4*>(Wl + (size_t)((wk * KB4 + st_ * 6 + q_) * 64 + lane) * 4);
                 };
-                f32x4 bq = ldsB(0, 0);
+                f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!BF) bq = ldsB(0, 0);
 #pragma unroll
                 for (int st = 0; st < NH; ++st) {
                     const int issued = (NB + st < NH) ? NB + st : NH;                       // pieces issued so far
@@ -1444,9 +1525,18 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                     else asm_wait6<0>(hv[st % NB]);
                     if (st == 0) { acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                    for (int q = 0; q < PQ; ++q)
-                        mx = max(max(mx, max(hv[st % NB][q].x, hv[st % NB][q].y)), max(hv[st % NB][q].z, hv[st % NB][q].w));
+                    for (int q = 0; q < PQ; ++q) {
+                        if constexpr (BF) mx = pk_max_u16(pk_max_u16(mx, pk_max_u16(hv[st % NB][q].x, hv[st % NB][q].y)), pk_max_u16(hv[st % NB][q].z, hv[st % NB][q].w));
+                        else mx = max(max(mx, max(hv[st % NB][q].x, hv[st % NB][q].y)), max(hv[st % NB][q].z, hv[st % NB][q].w));
+                    }
                     asm volatile("" : "+v"(mx));
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int q = 0; q < PQ; ++q) {          // a loaded 16-byte piece is the MFMA operand as it stands
+                            const bf16x8 b8 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + (size_t)((wk * (KB4 / 2) + st * PQ + q) * 64 + lane) * 4));
+                            acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hv[st % NB][q]), b8, acc[q & 1], 0, 0, 0);
+                        }
+                    } else
 #pragma unroll
                     for (int q = 0; q < PQ; ++q) {
                         const f32x4 b = bq;
@@ -1460,16 +1550,18 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                     if (st + NB < NH) issue_piece(st + NB, hv[st % NB], voff);
                 }
                 sum = acc[0] + acc[1];
+                if constexpr (BF) return __any(any_half_sentinel(mx));
                 return __any(mx == kSentinel);
             };
             auto probe = [&](SpinGuard& sg) __attribute__((always_inline)) {
                 // start signal (heuristic): lane l reads the last element producer l&31 stores for the team's last row
                 const int len_p = PIPE ? (j_rev ? p_lens[row0 + 15] : 0) : len_p0;      // (one row block: fetched once, before the loop)
-                const float* pp = xg + xch_index(pos_map(p + 1, len_p, j_rev), row0 + 15, (ln_l & 31) * 48 + 47, B, 3 * D);
+                const float* pp = BF ? xg + (xch16_index(pos_map(p + 1, len_p, j_rev), row0 + 15, (ln_l & 31) * 48 + 47, B, 3 * D) >> 1)      // (the high half of its dword)
+                                     : xg + xch_index(pos_map(p + 1, len_p, j_rev), row0 + 15, (ln_l & 31) * 48 + 47, B, 3 * D);
                 for (;;) {
                     unsigned v = 0u;
                     if (ln_l < 32) v = load4_sc1(pp);              // 32 cache lines per poll: half the wave stays out of it
-                    if (!__any(v == kSentinel) || sg.expired(p_err)) break;
+                    if (!__any(BF ? (v >> 16) == 0xffffu : v == kSentinel) || sg.expired(p_err)) break;
                 }
             };
             SpinGuard sg;
@@ -1524,8 +1616,18 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             const float dn = dH * (1.f - u) * (1.f - nn * nn);
             const float du = dH * (s_hp - nn) * u * (1.f - u);
             const float dr = dn * sv.w * r_ * (1.f - r_);
-            const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
-            {   // exchanged stores first (tiled buffer, gate-major: gate g of this unit sits 4 chunks = 1 KB after gate g - 1)
+            if constexpr (BF) {   // exchanged stores first: bf16, gate g of this unit 2 chunks = 512 B after gate g - 1
+                const unsigned short x0 = bf16_not_sentinel(dr), x1 = bf16_not_sentinel(du), x2 = bf16_not_sentinel(dn * r_);
+                const unsigned o0 = xch16_index(gpos, grow, ht * 48 + gn_l, B, 3 * D) * 2u;
+                if (fast) {
+                    __builtin_amdgcn_raw_buffer_store_b16(x0, rs_dgh, (int)o0, 0, 0); __builtin_amdgcn_raw_buffer_store_b16(x1, rs_dgh, (int)(o0 + 512u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(x2, rs_dgh, (int)(o0 + 1024u), 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b16(x0, rs_dgh, (int)o0, 0, 16); __builtin_amdgcn_raw_buffer_store_b16(x1, rs_dgh, (int)(o0 + 512u), 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b16(x2, rs_dgh, (int)(o0 + 1024u), 0, 16);
+                }
+            } else {   // exchanged stores first (tiled buffer, gate-major: gate g of this unit sits 4 chunks = 1 KB after gate g - 1)
+                const float x0 = not_sentinel(dr), x1 = not_sentinel(du), x2 = not_sentinel(dn * r_);
                 const unsigned o0 = xch_index(gpos, grow, ht * 48 + gn_l, B, 3 * D) * 4u;
                 if (fast) { bstore1(x0, rs_dgh, o0); bstore1(x1, rs_dgh, o0 + 1024u); bstore1(x2, rs_dgh, o0 + 2048u); }
                 else { bstore1_sc1(x0, rs_dgh, o0); bstore1_sc1(x1, rs_dgh, o0 + 1024u); bstore1_sc1(x2, rs_dgh, o0 + 2048u); }
@@ -1659,8 +1761,9 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd, b
 {
     const size_t rows = (size_t)a.S * a.B, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
     if (team) {       // team kernels exchange through the tiled scratch buffer: one linear fill over every job's part
+        const size_t n16 = (size_t)a.njobs * rows * width / 4;             // (bf16 mode, backward: the exchange holds 16-bit values)
         hipLaunchKernelGGL(gru_prepare_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords,
-                           reinterpret_cast<uint4*>(a.xbuf), (size_t)a.njobs * rows * width / 4);
+                           reinterpret_cast<uint4*>(a.xbuf), (!fwd && a.bf16) ? n16 / 2 : n16);
         return hipGetLastError();
     }
     float* base0 = fwd ? a.job[0].hs : a.job[0].dgh;
@@ -1701,20 +1804,27 @@ static bool team_geometry(const GruArgs& a, bool fwd, int* T, int* C)
         *T = t; *C = 8;
         return true;
     }
+    // Batches too small to fill the chip in either form still run the team kernels, one row block per workgroup on
+    // njobs x blocks x 32 CUs -- the forms of the benchmark geometry (4 teams for the encoder's two directions, 2 teams for
+    // a decoder layer), which is what lets the B = 64 oracle fixtures of tests/test_gpu_round2.py reach them.
+    for (int i = 0; i < 2; ++i) {
+        const int t = (a.njobs == 2) == (i == 0) ? 4 : 2, rb = 16 * t;
+        if (a.B % rb == 0 && a.njobs * (a.B / rb) <= 8) { *T = t; *C = a.njobs * (a.B / rb); return true; }
+    }
     return false;
 }
 
 template <class K>
 static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int lds_bytes, int C)
 {
-    static const void* attr_done[8]; static int nattr = 0;
+    static const void* attr_done[32]; static int nattr = 0;
     const void* kp = reinterpret_cast<const void*>(kernel);
     bool seen = false;
     for (int i = 0; i < nattr; ++i) seen |= attr_done[i] == kp;
     if (!seen) {
         hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
-        if (nattr < 8) attr_done[nattr++] = kp;
+        if (nattr < 32) attr_done[nattr++] = kp;
     }
     const int grid = C * 32;
     hipError_t e = resident(kernel, 1024, lds_bytes, grid);
@@ -1746,6 +1856,10 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
             } else
 #endif
             {
+                if (a.bf16) {
+                    if (T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 4, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4, true>, a, lds_bytes, C);
+                    return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 2, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2, true>, a, lds_bytes, C);
+                }
                 if (T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4>, a, lds_bytes, C);
                 return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 2>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2>, a, lds_bytes, C);
             }
@@ -1781,6 +1895,10 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
                 return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2, true>, a, lds_bytes, C);
             }
 #endif
+            if (a.bf16) {
+                if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4, false, true>, a, lds_bytes, C);
+                return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2, false, true>, a, lds_bytes, C);
+            }
             if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4>, a, lds_bytes, C);
             return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2>, a, lds_bytes, C);
         }

@@ -48,6 +48,7 @@ struct avae_ctx {
     std::vector<int> hook_pending;     // buckets complete but not yet announced (see hook_flush)
     int persistent = 1;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
     std::vector<GruP> enc;     // per layer: W = [fwd;bwd] (6D,In), R = [fwd;bwd], bW (6D), bR (6D)
@@ -365,7 +366,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.gi = w.e_gi[i] + d * 3 * D;
@@ -408,7 +409,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.gi = w.d_gi[i]; j.R = h->P + p.R; j.bR = h->P + p.bR;
         j.h0 = state_in + state_stride * i;
@@ -503,7 +504,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
         j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
@@ -551,7 +552,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
@@ -793,6 +794,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_item")) { h->gru_item = value; return 0; }
     if (!strcmp(key, "gru_stagger")) { h->gru_stagger = value; return 0; }
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
+    if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");

@@ -377,8 +377,12 @@ def test_profile_flag_produces_a_kernel_profile_and_save_tf_writes_bundles(tmp_p
 # ------------------------------------------------------------------------------------------ BASELINE configs[2] at full size
 def test_configs2_full_size_bf16_properties():
     """BASELINE configs[2]: bf16 GEMM operands, batch 1024 x seq 128 (vocab 8k, latent 128) -- too large for any oracle,
-    so size-independent properties: rows are independent (the first 64 rows encode to the same z alone or inside the
-    full batch), every loss is finite, and the loss falls over a few Adam steps on one batch."""
+    so size-independent properties: rows are independent, every loss is finite, and the loss falls over a few Adam steps on
+    one batch.  Row independence is exact at one geometry (two 64-row blocks swapped: every row gets bit for bit the z it
+    had).  Across geometries (the first 64 rows alone run other kernel forms, which sum the same products in another
+    order) this mode agrees to bf16 accuracy only: the recurrent operand h is ROUNDED to bf16 at every step, and a last-bit
+    difference in h can flip that rounding (2^-9 relative) -- the fp32 mode holds 1e-5 there
+    (test_large_batch_rows_are_independent)."""
     import torch
     from argsim_amd import synth
     from argsim_amd.model import VAE
@@ -388,7 +392,11 @@ def test_configs2_full_size_bf16_properties():
     z_all = m.encode(ids)
     z_64 = m.encode(ids[:64])
     assert z_all.shape == (1024, 128) and np.isfinite(z_all).all()
-    assert np.abs(z_all[:64] - z_64).max() <= 1e-5
+    assert np.abs(z_all[:64] - z_64).max() <= 1e-2
+    swapped = ids.copy()
+    swapped[:64], swapped[64:128] = ids[64:128], ids[:64]
+    z_sw = m.encode(swapped)
+    assert np.array_equal(z_sw[64:128], z_all[:64]) and np.array_equal(z_sw[:64], z_all[64:128]) and np.array_equal(z_sw[128:], z_all[128:])
     dev = torch.as_tensor(ids).cuda()
     first = last = None
     for i in range(4):
