@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void cvt_transpose_bf16_kernel(const float* __
     __syncthreads();
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
-        int f = tid + 256 * rep, x = f & 63, kg = (f >> 6) << 3;
+        int f = tid + 256 * rep, x = f >> 3, kg = (f & 7) << 3;       // 8 consecutive lanes write one row's 128 contiguous bytes
         if (x0 + x < X && k0 + kg < ldk) {
             float v[8];
 #pragma unroll

@@ -103,7 +103,9 @@ struct PrepArgs {
     int32_t* cidx;      // (N) flat (t*B+b) of compact row
     int32_t* ntok;      // [0]=N
     float* zero2;       // optional: two floats cleared here (the loss accumulators), saves a memset launch
+    int32_t* chunk_counts;   // scratch, kPrepChunks ints: kept positions per chunk of the flat time-major order
 };
+constexpr int kPrepChunks = 1024;
 hipError_t prep_ids(hipStream_t st, const PrepArgs& p);
 
 hipError_t embed_gather(hipStream_t st, const float* E, const int32_t* ids, float* out, int n, int D, int V);

@@ -141,7 +141,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     const size_t T = St + 1, rs = (size_t)Ss * B, rt = T * B;
     w.src_tm = b.take<int32_t>(rs); w.lens_src = b.take<int32_t>(B); w.lens_tgt = b.take<int32_t>(B);
     w.lead = b.take<int32_t>(rt); w.gold = b.take<int32_t>(rt); w.rank = b.take<int32_t>(rt);
-    w.cidx = b.take<int32_t>(rt); w.ntok = b.take<int32_t>(4); w.pred = b.take<int32_t>(rt);
+    w.cidx = b.take<int32_t>(rt); w.ntok = b.take<int32_t>(4 + kPrepChunks); w.pred = b.take<int32_t>(rt);      // (ntok[4..]: prep_ids' chunk counts)
     w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
@@ -434,7 +434,7 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     p.src = src; p.tgt = tgt; p.B = B; p.Ss = Ss; p.St = St; p.eos = h->cfg.eos; p.bos = h->cfg.bos;
     p.train = train ? 1 : 0; p.keepwd = sc.keepwd; p.seed = seed; p.keep_mask = keep_mask;
     p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
-    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.zero2 = h->acc;
+    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4; p.zero2 = h->acc;
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
@@ -933,7 +933,7 @@ int avae_encode(avae_handle h, const int32_t* src, int32_t b, int32_t t, float* 
     PrepArgs p{};
     p.src = src; p.tgt = src; p.B = b; p.Ss = t; p.St = 1; p.eos = h->cfg.eos; p.bos = h->cfg.bos;
     p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
-    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok;
+    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4;
     // tgt is unused by the encoder; feed the first column of src as a 1-wide dummy target
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(run_encoder(h, w, b, t, false));

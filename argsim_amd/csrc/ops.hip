@@ -1,6 +1,7 @@
 // ops.hip -- the HBM-bound kernels of the VAE step: id preparation, embedding gather /
 // scatter-add, compaction, final-state pick, latent elementwise, softmax cross-entropy,
 // column sums, TF-style Adam, layout permutation.  Each cites the reference lines it replaces.
+#include <algorithm>
 #include "kernels.h"
 
 namespace avae {
@@ -29,65 +30,103 @@ __device__ __forceinline__ float normal01(uint64_t seed, uint64_t stream, uint64
 // ---------------------------------------------------------------- prep_ids
 // src/model.py:82-95 + src/util_tf.py:40-57: transpose to time-major, lengths, decoder mask,
 // gold = tgt + [eos], lead = [bos] + word-dropout(tgt), and the time-major compaction index
-// that tf.boolean_mask (model.py:161,174) implies.  One workgroup; the arrays are tiny.
-__global__ __launch_bounds__(1024) void prep_ids_kernel(PrepArgs p)
+// that tf.boolean_mask (model.py:161,174) implies.
+// Two launches over the whole chip (one workgroup took 73 us at 256 x 64 and 570 us at 1024 x 128): the first does
+// everything elementwise -- lengths (a wave per row), transposes, lead / gold -- and counts the kept positions of each
+// contiguous chunk of the flat time-major order; the second turns the chunk counts into the compaction index (every
+// workgroup sums the counts before its own chunk, then scans its chunk).
+__device__ __forceinline__ bool prep_kept(const PrepArgs& p, int i)     // decoder mask of flat time-major position i
 {
-    __shared__ int sums[1024];
-    const int tid = threadIdx.x, B = p.B, T = p.St + 1;
-    for (int b = tid; b < B; b += 1024) {
+    const int t = i / p.B, b = i - t * p.B;
+    return t == 0 || p.tgt[(size_t)b * p.St + t - 1] != p.eos;
+}
+__device__ __forceinline__ int block_sum256(int v, int* red)            // sum over the 256 threads, returned to all
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return s;
+}
+__global__ __launch_bounds__(256) void prep_ids_kernel(PrepArgs p, int per, int nchunks)
+{
+    __shared__ int red[4];
+    const int tid = threadIdx.x, lane = tid & 63, B = p.B, T = p.St + 1, total = T * B;
+    const int nthr = gridDim.x * 256, gid = blockIdx.x * 256 + tid;
+    for (int b = gid >> 6; b < B; b += nthr >> 6) {
         int ls = 0, lt = 0;
-        for (int s = 0; s < p.Ss; ++s) ls += p.src[(size_t)b * p.Ss + s] != p.eos;
-        for (int s = 0; s < p.St; ++s) lt += p.tgt[(size_t)b * p.St + s] != p.eos;
-        p.lens_src[b] = ls; p.lens_tgt[b] = lt;
+        for (int s = lane; s < p.Ss; s += 64) ls += p.src[(size_t)b * p.Ss + s] != p.eos;
+        for (int s = lane; s < p.St; s += 64) lt += p.tgt[(size_t)b * p.St + s] != p.eos;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o); lt += __shfl_xor(lt, o); }
+        if (lane == 0) { p.lens_src[b] = ls; p.lens_tgt[b] = lt; }
     }
-    for (int i = tid; i < p.Ss * B; i += 1024) {
-        int s = i / B, b = i - s * B;
+    for (int i = gid; i < p.Ss * B; i += nthr) {
+        const int s = i / B, b = i - s * B;
         p.src_tm[i] = p.src[(size_t)b * p.Ss + s];
     }
-    const int total = T * B;
-    for (int i = tid; i < total; i += 1024) {
-        int t = i / B, b = i - t * B;
+    for (int i = gid; i < total; i += nthr) {
+        const int t = i / B, b = i - t * B;
         p.gold[i] = t < p.St ? p.tgt[(size_t)b * p.St + t] : p.eos;
         int lead = p.bos;
         if (t > 0) {
             lead = p.tgt[(size_t)b * p.St + t - 1];
             if (p.train) {
-                int j = (t - 1) * B + b;
-                bool keep = p.keep_mask ? p.keep_mask[j] != 0 : uniform01(p.seed, 1, j) < p.keepwd;
+                const int j = (t - 1) * B + b;
+                const bool keep = p.keep_mask ? p.keep_mask[j] != 0 : uniform01(p.seed, 1, j) < p.keepwd;
                 if (!keep) lead = 0;     // unk, model.py:94
             }
         }
         p.lead[i] = lead;
     }
-    // exclusive scan of the mask in flat time-major order: contiguous segment per thread
-    const int per = (total + 1023) / 1024;
-    const int beg = min(total, tid * per), end = min(total, beg + per);
+    if (gid < 2 && p.zero2) p.zero2[gid] = 0.f;
+    if ((int)blockIdx.x < nchunks) {
+        const int beg = blockIdx.x * per, end = min(total, beg + per);
+        int cnt = 0;
+        for (int i = beg + tid; i < end; i += 256) cnt += prep_kept(p, i);
+        cnt = block_sum256(cnt, red);
+        if (tid == 0) p.chunk_counts[blockIdx.x] = cnt;
+    }
+}
+__global__ __launch_bounds__(256) void prep_rank_kernel(PrepArgs p, int per)
+{
+    __shared__ int red[4];
+    __shared__ int scan[256];
+    const int tid = threadIdx.x, total = (p.St + 1) * p.B;
+    int pre = 0;
+    for (int c = tid; c < (int)blockIdx.x; c += 256) pre += p.chunk_counts[c];
+    pre = block_sum256(pre, red);
+    // a contiguous run of per / 256 positions per thread, exclusive scan of the run counts over the workgroup
+    const int ept = per >> 8, beg = min(total, (int)blockIdx.x * per + tid * ept), end = min(total, beg + ept);
     int cnt = 0;
-    for (int i = beg; i < end; ++i) {
-        int t = i / B, b = i - t * B;
-        cnt += (t == 0) || (p.tgt[(size_t)b * p.St + t - 1] != p.eos);
-    }
-    sums[tid] = cnt;
+    for (int i = beg; i < end; ++i) cnt += prep_kept(p, i);
+    scan[tid] = cnt;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = tid >= off ? sums[tid - off] : 0;
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? scan[tid - off] : 0;
         __syncthreads();
-        sums[tid] += v;
+        scan[tid] += v;
         __syncthreads();
     }
-    int run = sums[tid] - cnt;
+    int run = pre + scan[tid] - cnt;
     for (int i = beg; i < end; ++i) {
-        int t = i / B, b = i - t * B;
-        bool m = (t == 0) || (p.tgt[(size_t)b * p.St + t - 1] != p.eos);
+        const bool m = prep_kept(p, i);
         p.rank[i] = m ? run : -1;
         if (m) p.cidx[run++] = i;
     }
-    if (tid == 1023) p.ntok[0] = sums[1023];
-    if (tid < 2 && p.zero2) p.zero2[tid] = 0.f;
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) p.ntok[0] = pre + scan[255];
 }
 hipError_t prep_ids(hipStream_t st, const PrepArgs& p)
 {
-    hipLaunchKernelGGL(prep_ids_kernel, dim3(1), dim3(1024), 0, st, p);
+    const int total = (p.St + 1) * p.B;
+    int per = 2048;                                         // positions per chunk: a multiple of 256, at most kPrepChunks chunks
+    while ((total + per - 1) / per > kPrepChunks) per *= 2;
+    const int nchunks = (total + per - 1) / per;
+    const int grid = std::max(nchunks, std::min(1024, (total + 255) / 256));
+    hipLaunchKernelGGL(prep_ids_kernel, dim3(grid), dim3(256), 0, st, p, per, nchunks);
+    hipLaunchKernelGGL(prep_rank_kernel, dim3(nchunks), dim3(256), 0, st, p, per);
     return hipGetLastError();
 }
 
