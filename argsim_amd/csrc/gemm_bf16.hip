@@ -10,6 +10,7 @@
 // One GEMM layout only: C[M,N] = alpha * A[M,K] * B[N,K]^T with both operands k-contiguous bf16.  fp32
 // operands that are stored [k][x] (the NN / TN cases of the fp32 kernel) are transposed while they are
 // converted, so the GEMM never needs a transposing LDS access.
+#include <algorithm>
 #include "kernels.h"
 
 namespace avae {
@@ -221,12 +222,187 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBf16Args g)
     }
 }
 
+// ---------------------------------------------------------------- the large-tile form
+// The 128x128 kernel above asks the CU's vector-memory path for 64 B/clk at full matrix rate (32 KB of operands per 16 MFMAs
+// of 32 cycles with four workgroups sharing the SIMDs) -- exactly what that path delivers, so it cannot pass ~half rate
+// (measured 630 TFLOP/s on the shapes of configs[2]).  Block tile 256x256x64 halves the operand bytes per FLOP: one
+// 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), each 4 x 2 MFMA tiles of 32x32 (128 accumulator registers); the
+// same padded k-contiguous LDS image, two buffers (144 KB), ONE barrier per K tile: the next tile's global loads are
+// issued before the 32 MFMAs of this tile and written to the other buffer after them.
+constexpr int T2 = 256;
+constexpr int kBigLds = 2 * 2 * T2 * LDH * 2;        // bytes: [buffer][A | B][256 rows][LDH] bf16
+
+__device__ __forceinline__ void load_panel256(uint4 (&r)[4], const unsigned short* __restrict__ P, int ld, int x0, int X,
+                                              int k0, int K, int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const int f = tid + 512 * rep, x = x0 + (f >> 3), k = k0 + ((f & 7) << 3);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (x < X && k < K) {
+            v = *reinterpret_cast<const uint4*>(P + (size_t)x * ld + k);
+            if (k + 8 > K) {            // K tail inside this vector (device-side K): drop the elements >= K
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k + e >= K) w[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        r[rep] = v;
+    }
+}
+__device__ __forceinline__ void store_panel256(unsigned short* __restrict__ s, const uint4 (&r)[4], int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const int f = tid + 512 * rep;
+        *reinterpret_cast<uint4*>(s + (f >> 3) * LDH + ((f & 7) << 3)) = r[rep];
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_nt256_kernel(GemmBf16Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int M = g.M, K = g.K;
+    if (g.dyn_kind == 1) M = min(M, *g.dyn);
+    if (g.dyn_kind == 2) K = min(K, *g.dyn);
+    const int tiles_n = (g.N + T2 - 1) / T2;
+    int bid = blockIdx.x;
+    {
+        const int nblk = ((M + T2 - 1) / T2) * tiles_n;     // effective tiles (device-side row count), <= gridDim.x
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        if (slot >= q + (xcd < r ? 1 : 0)) return;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * T2, n0 = tn * T2;
+    if (m0 >= M) return;
+    int kb = 0, ke = K;
+    if (g.split_k > 1) {
+        const int ktiles = (K + BKH - 1) / BKH, per = (ktiles + g.split_k - 1) / g.split_k;
+        kb = blockIdx.z * per * BKH; ke = min(K, kb + per * BKH);
+        if (kb >= ke) return;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    load_panel256(ra, g.A, g.lda, m0, M, kb, ke, tid);
+    load_panel256(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    store_panel256(smem2, ra, tid);
+    store_panel256(smem2 + T2 * LDH, rb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += BKH, cur ^= 1) {
+        const bool more = k0 + BKH < ke;
+        if (more) {
+            load_panel256(ra, g.A, g.lda, m0, M, k0 + BKH, ke, tid);
+            load_panel256(rb, g.B, g.ldb, n0, g.N, k0 + BKH, ke, tid);
+        }
+        const unsigned short* As = smem2 + cur * (2 * T2 * LDH);
+        const unsigned short* Bs = As + T2 * LDH;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (128 * wm + 32 * t + l31) * LDH + 16 * s + 8 * h));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (64 * wn + 32 * t + l31) * LDH + 16 * s + 8 * h));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            unsigned short* An = smem2 + (cur ^ 1) * (2 * T2 * LDH);
+            store_panel256(An, ra, tid);
+            store_panel256(An + T2 * LDH, rb, tid);
+        }
+        __syncthreads();
+    }
+    const bool atomic = g.split_k > 1;
+    const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
+    if (m0 + T2 <= M && n0 + T2 <= g.N && !atomic) {
+        // a tile wholly inside the matrix: straight-line stores, one address computation per 32x32 tile (the per-element
+        // form below -- row predicate, three-way mode branch -- is ~40 instructions x 128 elements per lane: longer than the
+        // K = 512 main loop, and with one workgroup per CU nothing runs beside it)
+        const size_t ldc = (size_t)g.ldc;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + l31;
+            const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* c0 = g.C + (size_t)(m0 + 128 * wm + 32 * i + 4 * h) * ldc + col;
+                if (g.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { float* c = c0 + (size_t)((r & 3) + 8 * (r >> 2)) * ldc; *c += g.alpha * acc[i][j][r] + bv; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c0[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = g.alpha * acc[i][j][r] + bv;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 64 * wn + 32 * j + l31;
+        if (col >= g.N) continue;
+        const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 128 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                const float v = g.alpha * acc[i][j][r] + bv;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
 // operands already converted: A [M][lda] bf16, B [N][ldb] bf16, lda/ldb multiples of 8
 hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g)
 {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if ((lda | ldb) & 7) return hipErrorInvalidValue;
     GemmBf16Args a{A, B, g.C, g.bias, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, g.accumulate, g.split_k, g.dyn, g.dyn_kind};
+    // large tiles where they fill the chip, by themselves or through the K split (a caller's split was sized for 128x128
+    // tiles at three workgroups per CU; here one workgroup per CU, so it is re-derived: ~2 rounds of 256 workgroups)
+    const int big_tiles = ((g.M + T2 - 1) / T2) * ((g.N + T2 - 1) / T2);
+    int s2 = g.split_k > 1 ? (512 + big_tiles / 2) / big_tiles : 1;
+    s2 = std::max(1, std::min(std::min(s2, 16), std::max(1, g.K / (4 * BKH))));      // (more slices: the float atomics dominate)
+    if (g.N >= 192 && g.M >= 192 && big_tiles * s2 >= 200) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        a.split_k = s2;
+        if (g.split_k > 1 && s2 == 1) a.accumulate = 1;       // the caller's slices were going to ADD into C
+        dim3 grid(big_tiles, 1, s2);
+        hipLaunchKernelGGL(gemm_bf16_nt256_kernel, grid, dim3(512), kBigLds, st, a);
+        return hipGetLastError();
+    }
     int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, st, a);

@@ -412,10 +412,11 @@ def test_training_driver_end_to_end(tmp_path):
 
 # ---------------------------------------------------------------- bf16 GEMM-operand mode (BASELINE configs[2])
 @pytest.mark.parametrize("a_mc,b_nc", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 52), (333, 260, 132), (64, 512, 1000)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 52), (333, 260, 132), (64, 512, 1000), (4099, 3100, 200), (1024, 768, 8192)])
 def test_gemm_bf16_operands(a_mc, b_nc, M, N, K):
     """bf16 mode: operands rounded to bf16 (RNE), products accumulated in fp32.  Against float64 products of the
-    SAME rounded operands the only error left is fp32 accumulation order."""
+    SAME rounded operands the only error left is fp32 accumulation order.  The last two shapes run the 256x256-tile
+    kernel (ragged edges, one slice; K split into atomically added slices)."""
     import torch
     from argsim_amd import lib
     l = lib.load()
