@@ -237,6 +237,28 @@ __device__ __forceinline__ void frag_ensure(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc
         do { frag_issue<NQ>(v, rs, off, qstride); } while (frag_bad<NQ>(v) && !sg.expired(err));
     }
 }
+// the same for a 16-bit exchange: "not yet written" is the halfword 0xFFFF (one running v_pk_max_u16)
+template <int NQ>
+__device__ __forceinline__ bool frag_bad16(const u32x4 (&v)[NQ])
+{
+    unsigned mx = 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), v[q].x), __builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), v[q].y)));
+        const unsigned b = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), v[q].z), __builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), v[q].w)));
+        const unsigned c = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), a), __builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), b)));
+        mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), mx), __builtin_bit_cast(unsigned short __attribute__((ext_vector_type(2))), c)));
+    }
+    return __any((mx & 0xffffu) == 0xffffu || (mx >> 16) == 0xffffu);
+}
+template <int NQ>
+__device__ __forceinline__ void frag_ensure16(u32x4 (&v)[NQ], __amdgpu_buffer_rsrc_t rs, unsigned off, int* err, unsigned qstride)
+{
+    if (frag_bad16<NQ>(v)) {
+        SpinGuard sg;
+        do { frag_issue<NQ>(v, rs, off, qstride); } while (frag_bad16<NQ>(v) && !sg.expired(err));
+    }
+}
 
 // Hand-counted form of the same pipeline for the D = 512 backward pass.  hipcc's waitcnt insertion falls
 // back to vmcnt(0) around the re-load branches of frag_ensure, which serialises every piece behind a
@@ -794,9 +816,13 @@ __device__ __forceinline__ TeamMap team_map(const GruArgs& a, int rows_per_block
 // blocks, T = 2 (32 rows, K split over 8 waves: half the MFMAs and half the operand bytes per wave and step on the
 // latency chain) where it does not, e.g. one decoder layer at B = 256.
 // BF (bf16-operand mode, compute_dtype 1): the recurrent product h R' rounds both operands to bf16 like every other
-// contraction of that mode -- weights packed as bf16 in LDS (48 KB), the fp32 A fragment converted in registers,
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (12 MFMAs of 16 cycles per wave and item instead of 96 of 32).  The
-// exchange, the state h, the gate math and everything saved stay fp32.
+// contraction of that mode -- weights packed as bf16 in LDS (48 KB), v_mfma_f32_16x16x32_bf16 with fp32 accumulation (12
+// MFMAs of 16 cycles per wave and item instead of 96 of 32).  The exchange is 16-bit as in the backward (xch16_index: a
+// loaded 16-byte piece is the MFMA operand; half the bytes and half the load instructions through the texture addresser),
+// with one extra position in front: slot 0 holds h0 (or zeros), written by the launcher (gru_prepare16_kernel), so step 0
+// reads its operand like any other step; h_t lands in slot pos + 1.  The state h itself stays fp32: every gate thread keeps
+// the h_{t-1} of its (row, unit) in a register (one per row block) instead of picking it out of the exchanged operand; the
+// gate math and everything saved stay fp32.
 template <bool DIAG, bool PIPE, int T, bool BF = false>
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
@@ -824,11 +850,11 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int B = a.B;
 
     // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
-    if constexpr (BF) {   // block (wk', gate, q2): the lane's 8 bf16 = the k of fp32 blocks 2 q2 and 2 q2 + 1, 16 bytes per lane
+    if constexpr (BF) {   // block (wk', gate, q2): lane (n, kh) holds the 8 bf16 R'[ht*48 + n*3 + gate][wk'*WK + 32 q2 + 8 kh + e], e = 0..7
         for (int blk = wave; blk < 48; blk += 16) {
             const int wq = blk / (3 * (NQ / 2)), gate = (blk / (NQ / 2)) % 3, q2 = blk % (NQ / 2);
-            const float* rp = J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 32 * q2 + 4 * kh;
-            const float4 v0 = *reinterpret_cast<const float4*>(rp), v1 = *reinterpret_cast<const float4*>(rp + 16);
+            const float* rp = J.R + (size_t)(ht * 48 + n * 3 + gate) * D + wq * WK + 32 * q2 + 8 * kh;
+            const float4 v0 = *reinterpret_cast<const float4*>(rp), v1 = *reinterpret_cast<const float4*>(rp + 4);
             const u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
             *reinterpret_cast<u32x4*>(Wl + (size_t)blk * 256 + lane * 4) = pk;
         }
@@ -851,7 +877,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     float* __restrict__ p_svw = J.sv;                       // written only, under no other name: later loads need not wait for them
     float* __restrict__ p_hpw = J.hp;
     float* __restrict__ p_hsw = J.hs;
-    float* const xh = a.xbuf + (size_t)tm.jb * a.S * B * D;          // this job's exchange buffer (tiled, sentinel-filled)
+    // this job's exchange buffer (tiled, sentinel-filled; BF: S + 1 positions of 16-bit values)
+    float* const xh = BF ? a.xbuf + (size_t)tm.jb * (a.S + 1) * B * D / 2 : a.xbuf + (size_t)tm.jb * a.S * B * D;
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(xh), rs_h0 = make_rsrc(J.h0 ? J.h0 : xh);
     const __amdgpu_buffer_rsrc_t rs_gi = make_rsrc(p_gi), rs_hsw = make_rsrc(p_hsw);
     const __amdgpu_buffer_rsrc_t rs_svw = make_rsrc(p_svw ? p_svw : p_hsw), rs_hpw = make_rsrc(p_hpw ? p_hpw : p_hsw);
@@ -881,21 +908,24 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     // behind the MFMAs of the others (software pipelining over the row blocks; time is then linear in rows at the
     // matrix-pipe rate instead of at the chain latency).
     unsigned it = 0;                                          // items done so far (monotonic; LDS epochs derive from it)
-    u32x4 ra[NQ];
+    constexpr int NQA = BF ? NQ / 2 : NQ;                    // 16-byte pieces of the A fragment per lane
+    u32x4 ra[NQA];
+    float hc = 0.f, hc0 = 0.f, hc1 = 0.f, hc2 = 0.f, hc3 = 0.f;      // BF: this thread's h_{t-1} (!PIPE: one row block; PIPE: per row block)
     // byte offset of this lane's first 16-byte piece: step 0 reads the row-major h0 (pieces 64 B apart), later steps
-    // the tiled exchange (pieces 1 KB apart)
+    // the tiled exchange (pieces 1 KB apart); BF: always the exchange, whose slot 0 holds h0
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {
+        if constexpr (BF) return xch_lane_offset(p == 0 ? 0 : pos_map(p - 1, len_a, J.reverse) + 1, row0, wk * (WK / 8), n, kh, B, D / 2);
         if (p == 0) return (unsigned)((size_t)(row0 + n) * D * 4) + (wk * WK + 4 * kh) * 4;
         return xch_lane_offset(pos_map(p - 1, len_a, J.reverse), row0, wk * (WK / 4), n, kh, B, D);
     };
-    auto q_stride = [&](int p) -> unsigned { return p == 0 ? 64u : 1024u; };
+    auto q_stride = [&](int p) -> unsigned { return (p == 0 && !BF) ? 64u : 1024u; };
     auto next_frag = [&](int p2, int r2, int len2) __attribute__((always_inline)) {   // PIPE: issue (or zero) the fragment of item (p2, r2)
-        if (p2 > 0 || J.h0 != nullptr) {
+        if (BF || p2 > 0 || J.h0 != nullptr) {
             const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
-            frag_issue<NQ>(ra, (p2 == 0) ? rs_h0 : rs_hs, a_offset(p2, row2, len2), q_stride(p2));
+            frag_issue<NQA>(ra, (p2 == 0 && !BF) ? rs_h0 : rs_hs, a_offset(p2, row2, len2), q_stride(p2));
         } else {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
+            for (int q = 0; q < NQA; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
     };
     // sequence lengths of the rows this lane touches in the current item (A rows: n, gate rows: tid's row)
@@ -911,10 +941,11 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         const int grow = row0 + gr;
         const int gpos = pos_map(p, len_g, J.reverse);
         const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)grow;      // (byte offsets below 2^32: team_geometry checks)
-        float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f;
+        float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, h0_own = 0.f;
         if (gate_thread) {
             const u32x3 g3 = __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)((rix * (unsigned)a.ldg + ht * 48 + gn * 3) * 4u), 0, 0);
             gi0 = __uint_as_float(g3.x); gi1 = __uint_as_float(g3.y); gi2 = __uint_as_float(g3.z);
+            if constexpr (BF) { if (p == 0 && J.h0 != nullptr) h0_own = bload1(rs_h0, ((unsigned)grow * D + j) * 4u); }
         }
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
         const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p + 1;
@@ -926,10 +957,10 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             }
         }
         // (2) A operand: this wave's K quarter of the team's 16 rows
-        const bool have = p > 0 || J.h0 != nullptr;
+        const bool have = BF || p > 0 || J.h0 != nullptr;
         if (have) {
             const unsigned aoff = a_offset(p, row0, len_a);
-            const __amdgpu_buffer_rsrc_t rs = (p == 0) ? rs_h0 : rs_hs;
+            const __amdgpu_buffer_rsrc_t rs = (p == 0 && !BF) ? rs_h0 : rs_hs;
             if constexpr (!PIPE) {
                 if (poll) {
                     // ONE wave per team polls the exchange and releases its three K-split partners through an LDS
@@ -940,20 +971,21 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                     if (wk == 0) {
                         const int prow = row0 + 15;
                         const int plen = len_p0;                     // (!PIPE: one row block, fetched once before the loop)
-                        const float* pp = xh + xch_index(pos_map(p - 1, plen, J.reverse), prow, (lane & 31) * 16 + 15, B, D);
+                        const float* pp = BF ? xh + (xch16_index(pos_map(p - 1, plen, J.reverse) + 1, prow, (lane & 31) * 16 + 15, B, D) >> 1)      // (the high half of its dword)
+                                             : xh + xch_index(pos_map(p - 1, plen, J.reverse), prow, (lane & 31) * 16 + 15, B, D);
                         SpinGuard sg;
-                        while (__any(load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                        while (__any(BF ? (load4_sc1(pp) >> 16) == 0xffffu : load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
                         if (lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
                         while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                frag_issue<NQ>(ra, rs, aoff, q_stride(p));
+                frag_issue<NQA>(ra, rs, aoff, q_stride(p));
             }
-            if (poll) frag_ensure<NQ>(ra, rs, aoff, a.err, q_stride(p));
+            if (poll) { if constexpr (BF) frag_ensure16<NQA>(ra, rs, aoff, a.err, q_stride(p)); else frag_ensure<NQA>(ra, rs, aoff, a.err, q_stride(p)); }
         } else if constexpr (!PIPE) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
+            for (int q = 0; q < NQA; ++q) ra[q] = (u32x4){0u, 0u, 0u, 0u};
         }
         TSTAMP(0);
         // (3) MFMAs, B fragments from LDS
@@ -963,7 +995,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         if constexpr (BF) {
 #pragma unroll
             for (int q2 = 0; q2 < NQ / 2; ++q2) {
-                const bf16x8 a8 = pack_bf16x8(ra[2 * q2], ra[2 * q2 + 1]);
+                const bf16x8 a8 = __builtin_bit_cast(bf16x8, ra[q2]);       // a loaded 16-byte piece is the operand as it stands
 #pragma unroll
                 for (int gate = 0; gate < 3; ++gate) {
                     const bf16x8 b8 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + (size_t)((wk * 3 + gate) * (NQ / 2) + q2) * 256 + lane * 4));
@@ -1003,10 +1035,12 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
             *reinterpret_cast<f32x4*>(tpart + (wk * 3 + gate) * 256 + lane * 4) = acc[gate];
-        if (wk == own_wk) {
+        if constexpr (!BF) {
+            if (wk == own_wk) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (q == own_q) *reinterpret_cast<u32x4*>(thps + n * 16 + 4 * kh) = ra[q];
+                for (int q = 0; q < NQ; ++q)
+                    if (q == own_q) *reinterpret_cast<u32x4*>(thps + n * 16 + 4 * kh) = ra[q];
+            }
         }
         // (3b) PIPE: the NEXT item is another chain, whose operand every producer stored an item ago.  Its loads go in
         // flight now, into the registers the MFMAs have just released, and land behind the team barrier and the gate
@@ -1014,7 +1048,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         if constexpr (PIPE) {
             // (every load issued so far is retired HERE, on purpose: hipcc's waitcnt insertion merges the two sides of
             //  the branch below conservatively and would otherwise wait for the new fragment at the first use of gi)
-            asm volatile("" :: "v"(gi0), "v"(gi1), "v"(gi2), "v"(len2), "v"(len2g));
+            asm volatile("" :: "v"(gi0), "v"(gi1), "v"(gi2), "v"(h0_own), "v"(len2), "v"(len2g));
             __builtin_amdgcn_sched_barrier(0);
             if (p2 < a.p_end) next_frag(p2, r2, len2);
             __builtin_amdgcn_sched_barrier(0);
@@ -1033,11 +1067,24 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 for (int k = 0; k < KS; ++k) s4[k & 3] += tpart[(k * 3 + gate) * 256 + pidx];
                 gh[gate] = bR[gate] + ((s4[0] + s4[1]) + (s4[2] + s4[3]));
             }
-            const float hprev = thps[gr * 16 + gn];
+            float hprev;
+            if constexpr (BF) {     // the fp32 state of this (row, unit): in a register since the step before (step 0: h0 or zero)
+                if (p == 0) hprev = h0_own;
+                else if constexpr (PIPE) hprev = r == 0 ? hc0 : (r == 1 ? hc1 : (r == 2 ? hc2 : hc3));
+                else hprev = hc;
+            } else hprev = thps[gr * 16 + gn];
             const GruCellOut cell = gru_cell(gi0, gi1, gi2, gh[0], gh[1], gh[2], hprev);
             const float r_ = cell.r, u = cell.u, nn = cell.n, hnew = cell.h;
-            const unsigned xo = xch_index(gpos, grow, j, B, D) * 4u;      // exchanged store first
-            if (fast) bstore1(not_sentinel(hnew), rs_hs, xo); else bstore1_sc1(not_sentinel(hnew), rs_hs, xo);
+            if constexpr (BF) {      // exchanged store first: bf16, slot gpos + 1
+                const unsigned xo = xch16_index(gpos + 1, grow, j, B, D) * 2u;
+                if (fast) __builtin_amdgcn_raw_buffer_store_b16(bf16_not_sentinel(hnew), rs_hs, (int)xo, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b16(bf16_not_sentinel(hnew), rs_hs, (int)xo, 0, 16);
+                if constexpr (PIPE) { if (r == 0) hc0 = hnew; else if (r == 1) hc1 = hnew; else if (r == 2) hc2 = hnew; else hc3 = hnew; }
+                else hc = hnew;
+            } else {
+                const unsigned xo = xch_index(gpos, grow, j, B, D) * 4u;      // exchanged store first
+                if (fast) bstore1(not_sentinel(hnew), rs_hs, xo); else bstore1_sc1(not_sentinel(hnew), rs_hs, xo);
+            }
             bstore1(hnew, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);       // the row-major copy the GEMMs and the next layer read
             if (p_svw) bstore4(r_, u, nn, gh[2], rs_svw, ((rix * HT + ht) * 64 + gn * 4) * 4u);
             if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
@@ -1750,6 +1797,32 @@ __global__ __launch_bounds__(256) void gru_prepare_kernel(unsigned* sync_words, 
     const uint4 s4 = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
     for (; i < n16; i += stride) buf[i] = s4;
 }
+// bf16 mode, forward team kernels: the 16-bit exchange of every job = slot 0 seeded with h0 (zeros without one), converted
+// to bf16 in the tiled order of xch16_index, and S sentinel-filled slots behind it
+struct GruH0 { const float* p[kMaxGruJobs]; };
+__global__ __launch_bounds__(256) void gru_prepare16_kernel(unsigned* sync_words, int nsync, uint4* buf, size_t n16, size_t chunks_per_job,
+                                                            size_t seed_chunks, GruH0 h0s, int D)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)nsync) sync_words[i] = 0u;
+    const uint4 s4 = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+    for (; i < n16; i += stride) {
+        const size_t job = i / chunks_per_job, c = i - job * chunks_per_job;
+        uint4 v = s4;
+        if (c < seed_chunks) {              // chunk ((row/16) * D/8 + k/8) * 16 + row%16 of slot 0
+            v = make_uint4(0u, 0u, 0u, 0u);
+            const float* h0 = h0s.p[job];
+            if (h0) {
+                const size_t rb = c / ((size_t)(D >> 3) * 16), rem = c - rb * ((size_t)(D >> 3) * 16);
+                const size_t k8 = rem >> 4, row = rb * 16 + (rem & 15);
+                const float4 a0 = *reinterpret_cast<const float4*>(h0 + row * D + k8 * 8), a1 = *reinterpret_cast<const float4*>(h0 + row * D + k8 * 8 + 4);
+                v = make_uint4(pack_bf16(a0.x, a0.y), pack_bf16(a0.z, a0.w), pack_bf16(a1.x, a1.y), pack_bf16(a1.z, a1.w));
+            }
+        }
+        buf[i] = v;
+    }
+}
 static hipError_t fill_sentinel2d(hipStream_t st, float* base, size_t rows, size_t width, size_t ld)
 {
     return hipMemset2DAsync(base, ld * sizeof(float), 0xFF, width * sizeof(float), rows, st);
@@ -1760,6 +1833,14 @@ static hipError_t fill_sentinel2d(hipStream_t st, float* base, size_t rows, size
 static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd, bool team)
 {
     const size_t rows = (size_t)a.S * a.B, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
+    if (team && fwd && a.bf16) {
+        GruH0 h0s{};
+        for (int i = 0; i < a.njobs; ++i) h0s.p[i] = a.job[i].h0;
+        const size_t chunks_per_job = ((size_t)a.S + 1) * a.B * a.D / 8;
+        hipLaunchKernelGGL(gru_prepare16_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords, reinterpret_cast<uint4*>(a.xbuf),
+                           (size_t)a.njobs * chunks_per_job, chunks_per_job, (size_t)a.B * a.D / 8, h0s, a.D);
+        return hipGetLastError();
+    }
     if (team) {       // team kernels exchange through the tiled scratch buffer: one linear fill over every job's part
         const size_t n16 = (size_t)a.njobs * rows * width / 4;             // (bf16 mode, backward: the exchange holds 16-bit values)
         hipLaunchKernelGGL(gru_prepare_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords,

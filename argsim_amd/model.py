@@ -47,7 +47,7 @@ class VAE:
         self._l = _lib.load()
         self.device = torch.device('cuda', device)
         assert dtype in ('f32', 'bf16', 'f32s'), \
-            "dtype: 'f32' (fp32 MFMA, reference), 'f32s' (fp32 via split bf16 MFMA, fp32-accurate) or 'bf16' (bf16 GEMM operands)"
+            "dtype: 'f32' (fp32 MFMA, reference), 'f32s' (fp32 via split bf16 MFMA, fp32-accurate) or 'bf16' (bf16 operands in the GEMMs and the GRU recurrence, fp32 accumulate / state)"
         self.dtype = dtype
         c = _lib.AvaeConfig(dim_tgt, dim_emb, dim_rep, rnn_layers, accelerate, learn_rate, bos, eos, 0, 0, kl_beta, free_bits,
                             {'f32': 0, 'bf16': 1, 'f32s': 2}[dtype])

@@ -120,7 +120,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', default='f32', choices=('f32', 'f32s', 'bf16'),
                     help="f32 = exact-fp32 MFMA (headline); f32s = fp32 GEMMs on the bf16 matrix cores by 3-way operand "
-                         "splitting (fp32-accurate); bf16 = bf16 GEMM operands, fp32 everything else")
+                         "splitting (fp32-accurate); bf16 = bf16 operands in every contraction (GEMMs and the GRU recurrence), fp32 accumulate / state / Adam")
     ap.add_argument('--no-timing', action='store_true', help="skip the per-kernel HIP-event stamps (roofline leg)")
     ap.add_argument('--batch', type=int, default=B, help="rows per GPU (default: BASELINE configs[1]; 1024 = configs[2]/[3] per-GPU load)")
     ap.add_argument('--seq', type=int, default=S, help="sequence length (default 64; 128 = configs[2])")
@@ -222,12 +222,12 @@ def main():
             "n_gpus": world, "steps": A.steps, "warmup": A.warmup, "ms_per_step": 1e3 * dt / A.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f32s": "f32 (GEMM operands split into 3 x bf16 in registers, 6 partial products, f32 accumulate)",
-                      "bf16": "bf16 GEMM operands, f32 accumulate/recurrence/state/Adam"}[A.dtype], "data": "synthetic",
+                      "bf16": "bf16 operands in every contraction (GEMMs and the GRU recurrence), f32 accumulate/state/gate math/Adam"}[A.dtype], "data": "synthetic",
             "config": {"workload": ("" if headline else "NOT the headline workload (batch %d x seq %d per GPU%s) -- " % (B, S, ", RAGGED lengths" if A.ragged else "")) +
                                    "BASELINE configs[1]: 1xMI355X %s, latent_dim 128, vocab 8k, seq_len 64, batch 256 per GPU; "
                                    "FULL synthetic Zipf batches, dim_emb 512, 3 layers, step 20000"
                                    % {"f32": "fp32", "f32s": "fp32 (split-bf16 MFMA GEMMs, fp32-accurate)",
-                                      "bf16": "(bf16 GEMM operands: the opt-in mode of configs[2], same shapes)"}[A.dtype],
+                                      "bf16": "(bf16 operands: the opt-in mode of configs[2], same shapes)"}[A.dtype],
                        "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
                        "gru": "stepwise" if A.stepwise else "persistent"},
             "loss": losses[2],
@@ -290,7 +290,7 @@ def main():
                 pass
             torch.cuda.empty_cache()
             out["configs"] = {
-                "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 GEMM operands (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128),
+                "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 operands in the GEMMs and the GRU recurrence (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128),
                 "configs[3]/gpu": side_config("BASELINE configs[3] per-GPU load: fp32, batch 1024 (global 8192 over 8 GPUs), seq_len 64; the all-reduce is not part of it", 'f32', 1024, 64),
             }
         print(json.dumps(out))

@@ -46,7 +46,7 @@ typedef struct avae_config {
     float   kl_beta;      /* multiplies rate_anneal            */
     float   free_bits;    /* per-dimension KL floor (nats)     */
     int32_t compute_dtype;/* 0 = exact fp32 (reference);       */
-                          /* 1 = bf16 GEMM operands, fp32 accumulate/state/weights (BASELINE configs[2]) */
+                          /* 1 = bf16 operands in every contraction (GEMMs, GRU recurrence), fp32 accumulate/state/weights (BASELINE configs[2]) */
                           /* 2 = fp32 GEMMs on the bf16 matrix cores: each operand element split into 3 bf16 */
                           /*     in registers, 6 partial products, fp32 accumulate (fp32-accurate)          */
 } avae_config;
