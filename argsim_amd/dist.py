@@ -27,6 +27,12 @@ class GradReducer:
         self.group = group
         self.comm_stream = comm_stream
         self.pending = []
+        # RCCL runs a collective on the process group's own internal stream, ordered after the stream that was current at
+        # the call; Work.wait() then only makes the CURRENT stream wait for it (no host block).  Taken at once, inside the
+        # side-stream context, it puts the collective's completion INTO the side stream's order, so that fence() and
+        # wait() -- which order the compute stream after the side stream -- really are ordered after the collectives.
+        # (gloo completes on the host: its Work objects are kept and waited for where the results are needed.)
+        self.stream_ordered = comm_stream is not None and dist.get_backend(group) == 'nccl'
 
     def reduce_bucket(self, i):
         """all-reduce(sum) of bucket i; on a device, ordered after the work already enqueued on the
@@ -38,18 +44,24 @@ class GradReducer:
             ev.record(torch.cuda.current_stream(self.g.device))
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.stream_ordered:
+                    w.wait()
+                else:
+                    self.pending.append(w)
         else:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def fence(self):
         """the compute stream waits for every collective in flight (called before a persistent GRU launch)"""
-        if self.comm_stream is not None:
+        if self.stream_ordered:
             torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
         else:
             for w in self.pending:
                 w.wait()
             self.pending = []
+            if self.comm_stream is not None:
+                torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
 
     def wait(self):
         for w in self.pending:
