@@ -80,6 +80,41 @@ __global__ __launch_bounds__(256) void cvt_transpose_bf16_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------- bf16 [K][X] -> bf16 [X][ldk] (transpose of an operand
+// that already is bf16: the softmax gradient written by softmax_ce_kernel).  64x64 tiles through LDS, 16-byte accesses on
+// both sides; rows beyond K are zero-filled.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src, int ld, int K, int X,
+                                                             unsigned short* __restrict__ dst, int ldk)
+{
+    __shared__ unsigned short tile[64][72];
+    const int k0 = blockIdx.y * 64, x0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int f = tid + 256 * rep, k = f >> 3, xq = (f & 7) << 3;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (k0 + k < K && x0 + xq < X) v = *reinterpret_cast<const uint4*>(src + (size_t)(k0 + k) * ld + x0 + xq);
+        *reinterpret_cast<uint4*>(&tile[k][xq]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int f = tid + 256 * rep, x = f >> 3, kg = (f & 7) << 3;
+        if (x0 + x < X && k0 + kg < ldk) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (unsigned)tile[kg + 2 * e][x] | ((unsigned)tile[kg + 2 * e + 1][x] << 16);
+            *reinterpret_cast<uint4*>(dst + (size_t)(x0 + x) * ldk + k0 + kg) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+hipError_t transpose_bf16(hipStream_t st, const unsigned short* src, int ld, int K, int X, unsigned short* dst, int ldk)
+{
+    if ((ld | ldk) & 7 || X & 7) return hipErrorInvalidValue;
+    dim3 grid((X + 63) / 64, (ldk + 63) / 64);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, st, src, ld, K, X, dst, ldk);
+    return hipGetLastError();
+}
+
 hipError_t cvt_bf16(hipStream_t st, const float* src, int ld, bool transpose, int rows_or_K, int cols_or_X,
                     unsigned short* dst, int ldd)
 {

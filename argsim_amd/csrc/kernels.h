@@ -41,6 +41,8 @@ hipError_t cvt_bf16(hipStream_t st, const float* src, int ld, bool transpose, in
                     unsigned short* dst, int ldd);
 // C = alpha * A B^T (+bias)(+C): A [M][lda], B [N][ldb] bf16 k-contiguous; the other fields as in GemmArgs
 hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);
+// bf16 [K][X] (row stride ld) -> bf16 [X][ldk] (ldk = K rounded up to 8, pad zero-filled)
+hipError_t transpose_bf16(hipStream_t st, const unsigned short* src, int ld, int K, int X, unsigned short* dst, int ldk);
 
 // ---------------------------------------------------------------- GRU (gru.hip)
 // Gate-interleaved layout ("G16"): the 3D gate rows of W, R, bW, bR and the 3D columns of
@@ -136,6 +138,7 @@ struct CeArgs {
     int write_grad; float inv_n;   // scale; <= 0 -> 1 / *n_dev
     float* loss_samp; float* errt_samp; int32_t* pred;   // (N) optional
     float* loss_acc;          // [0] += sum loss_samp
+    unsigned short* grad16;   // optional (N,V) bf16: with write_grad the gradient goes HERE (the bf16 GEMM's operand panel) and the logits stay
 };
 hipError_t softmax_ce(hipStream_t st, const CeArgs& a);
 // pred[i] = argmax_j logits[i, j]  (first max), rows < n

@@ -68,6 +68,7 @@ struct avae_ctx {
     int timing = 0, timing_on = 0;
     // bf16-operand GEMM mode (compute_dtype = 1): converted operand panels
     unsigned short *bfA = nullptr, *bfB = nullptr; size_t bfA_cap = 0, bfB_cap = 0;
+    unsigned short* bfP = nullptr; size_t bfP_cap = 0;     // bf16 mode: (softmax - onehot)/N as written by softmax_ce_kernel, (N,V) bf16
     struct Stamp { hipEvent_t a, b; int cls; double flops; };
     std::vector<Stamp> stamps; size_t stamps_used = 0;
 };
@@ -245,6 +246,26 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
     // row panels (a few rows, little work) stay on the exact-fp32 kernel's 32x128 tiles
     if (h->cfg.compute_dtype == 2 && !thin) AV_CHECK(gemm_f32s(h->stream, a_mc, b_nc, g));
     else AV_CHECK(gemm_f32(h->stream, a_mc, b_nc, g));
+    return 0;
+}
+
+// bf16 mode, A already bf16 and row-major ((rows, lda16), written by the producer -- the softmax gradient): as the A panel
+// itself (a_mc = false: k-contiguous) or transposed once from the 2-byte source (a_mc = true); B converted as usual.
+int gemm_bf16_pre(avae_ctx* h, const unsigned short* A16, int lda16, bool a_mc, const float* Bm, int ldb, bool b_nc, float* C, int ldc,
+                  int M, int N, int K, float alpha, int accumulate, int split_k, const int* dyn, int dyn_kind)
+{
+    GemmArgs g{nullptr, Bm, C, nullptr, M, N, K, lda16, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, 0, nullptr, nullptr, nullptr, nullptr};
+    Timed t(h, 0, 2.0 * M * N * K);
+    const int Kp = (K + 7) & ~7;
+    const unsigned short* Ap = A16; int lda_p = lda16;
+    if (a_mc) {
+        AV_TRY(grow_bf16(h, &h->bfA, &h->bfA_cap, (size_t)M * Kp));
+        AV_CHECK(transpose_bf16(h->stream, A16, lda16, K, M, h->bfA, Kp));
+        Ap = h->bfA; lda_p = Kp;
+    }
+    AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)N * Kp));
+    AV_CHECK(cvt_bf16(h->stream, Bm, ldb, b_nc, b_nc ? K : N, b_nc ? N : K, h->bfB, Kp));
+    AV_CHECK(gemm_bf16_nt(h->stream, Ap, lda_p, h->bfB, Kp, g));
     return 0;
 }
 
@@ -447,6 +468,10 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     CeArgs c{};
     c.logits = w.logits; c.gold = w.gold; c.cidx = w.cidx; c.n_dev = w.ntok; c.n_max = rt; c.V = V;
     c.write_grad = train ? 1 : 0; c.inv_n = inv_n;
+    if (train && h->cfg.compute_dtype == 1 && (V & 7) == 0) {      // bf16 mode: the gradient is written as the backward GEMMs' bf16 operand
+        AV_TRY(grow_bf16(h, &h->bfP, &h->bfP_cap, (size_t)rt * V));
+        c.grad16 = h->bfP;
+    }
     c.loss_samp = w.loss_samp; c.errt_samp = w.errt_samp; c.pred = w.pred; c.loss_acc = h->acc;
     AV_CHECK(softmax_ce(h->stream, c));
     float beta = h->cfg.kl_beta;
@@ -486,10 +511,19 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_CHECK(hipMemsetAsync(G, 0, sizeof(float) * h->numel, st));
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
+    if (h->cfg.compute_dtype == 1 && (V & 7) == 0) {
+        // bf16 mode: softmax_ce_kernel left the gradient as bf16 (h->bfP): the first GEMM reads it as its A panel, the
+        // second transposes the 2-byte source once -- no fp32 gradient is written or converted (10.7 GB less traffic per
+        // step at configs[2]); same values as rounding the fp32 gradient, so the results do not change
+        AV_TRY(gemm_bf16_pre(h, h->bfP, V, false, P + h->oE, D, true, w.dho, D, rt, D, V, isd, 0, 1, w.ntok, 1));
+        const int s = grad_split(V, D, rt);
+        AV_TRY(gemm_bf16_pre(h, h->bfP, V, true, w.ho, D, true, G + h->oE, D, V, D, rt, isd, s > 1 ? 0 : 1, s, w.ntok, 2));
+    } else {
     AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1, true));
     // (V x D output over K = N rows: 1024 tiles of 64x64, one K slice, plain stores -- no atomics, deterministic; G was
     //  zero-filled above and the gather part is scatter-added at the end)
     AV_TRY(gemm_tn_grad(h, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, w.ntok));
+    }
     // out affine
     AV_TRY(gemm_tn_grad(h, w.hc, D, w.dho, D, G + h->oKout, D, D, D, rt, 1.f, w.ntok));
     AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));
@@ -715,6 +749,7 @@ void avae_destroy(avae_handle h)
     if (h->counters) (void)hipFree(h->counters);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->bfA) (void)hipFree(h->bfA);
+    if (h->bfP) (void)hipFree(h->bfP);
     if (h->bfB) (void)hipFree(h->bfB);
     delete h;
 }

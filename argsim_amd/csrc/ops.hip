@@ -394,6 +394,13 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
                 float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] = (expf(e[k] - lse) - ((c + k) == label ? 1.f : 0.f)) * scale;
+                if (a.grad16) {      // bf16 mode: the GEMM operand panel itself (RNE, what the conversion pass would have written)
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 lo = {e[0], e[1]}, hi = {e[2], e[3]};
+                    const uint2 pk = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf2)));
+                    *reinterpret_cast<uint2*>(a.grad16 + (size_t)row * a.V + c) = pk;
+                } else
                 *reinterpret_cast<float4*>(x + c) = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
