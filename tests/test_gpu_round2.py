@@ -307,6 +307,35 @@ def test_row_block_pipelined_team_kernels_equal_stepwise(B, S):
     assert all(np.isfinite(out[1][3]))
 
 
+@pytest.mark.parametrize("B,S", [(256, 16), (512, 20), (1024, 12)])
+def test_bf16_mode_team_kernels_track_the_register_form(B, S):
+    """bf16-operand mode (configs[2]) at D = 512: the team kernels -- bf16 weights in LDS, v_mfma_f32_16x16x32_bf16, the
+    16-bit exchange whose loaded piece is the MFMA operand, h0 seeded into slot 0, fp32 h_prev carried in registers; one row
+    block per workgroup (B = 256) and 2-4 pipelined row blocks (B >= 512) -- against one launch per step of the register-form
+    kernels, which round the same two operands to bf16 in fp32 registers.  Same products, another summation order, and
+    a last-bit difference in h can flip its bf16 rounding at the next step: agreement to bf16 accuracy (z 1e-2 abs,
+    losses 2e-3 rel, gradients 3e-2 rel-L2), not bit for bit.  The 16-bit exchange can be switched off (gru_bf16 = 0:
+    fp32 recurrence): the two modes of the recurrence agree at the same level."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=1, dtype='bf16', dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    ids = synth.batch(B, S, 8192, ragged=True, seed=7)
+    out = {}
+    for key, (persistent, gru_bf16) in {'team': (1, 1), 'stepwise': (0, 1), 'fp32rec': (1, 0)}.items():
+        m.set_option('persistent', persistent)
+        m.set_option('gru_bf16', gru_bf16)
+        z = m.encode(ids)
+        m.forward_backward(ids, ids, seed=5)
+        out[key] = (z, m.grads.clone(), m.losses())
+    for other in ('stepwise', 'fp32rec'):
+        assert np.isfinite(out['team'][0]).all() and np.abs(out['team'][0] - out[other][0]).max() <= 1e-2, other
+        assert abs(out['team'][2][2] - out[other][2][2]) <= 2e-3 * abs(out[other][2][2]), other
+        d = float((out['team'][1] - out[other][1]).norm() / out[other][1].norm())
+        assert d < 3e-2, (other, d)
+    m.close()
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f) row 2
 @pytest.mark.parametrize("b", [1, 5, 32])
 def test_persistent_greedy_decode_equals_the_per_token_loop(b):
