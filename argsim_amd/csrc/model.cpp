@@ -123,6 +123,7 @@ struct Ws {
     // backward
     float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
+    int32_t* scat;                        // embed_scatter_add2's token lists
     float* xbuf; size_t xbuf_floats;      // exchange scratch of the GRU team kernels (GruArgs::xbuf)
 };
 
@@ -184,6 +185,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.dhs[0] = b.take<float>(rs * 2 * D); w.dhs[1] = b.take<float>(rs * 2 * D);
         w.dgi_e = b.take<float>(rs * 6 * D); w.dgh_e = b.take<float>(rs * 6 * D);
         w.demb_src = b.take<float>(rs * D); w.demb_tgt = b.take<float>(rt * D);
+        w.scat = b.take<int32_t>(embed_scatter_scratch_ints(rs + rt, V));
     }
 }
 
@@ -611,8 +613,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         if (i == 0) hook_flush(h);         // no persistent launch follows: announce now, beside the embedding scatter-adds
     }
     // embedding: gather gradients on top of the logits term
-    AV_CHECK(embed_scatter_add(st, G + h->oE, w.src_tm, w.demb_src, rs, D, V));
-    AV_CHECK(embed_scatter_add(st, G + h->oE, w.lead, w.demb_tgt, rt, D, V));
+    AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, rt, D, V, w.scat));
     fire_hook(h, 2 + 2 * L);
     hook_flush(h);
     return 0;
