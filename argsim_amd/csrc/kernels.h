@@ -114,7 +114,7 @@ hipError_t embed_gather(hipStream_t st, const float* E, const int32_t* ids, floa
 // dE[ids0[t]] += dout0[t], dE[ids1[t]] += dout1[t]; scratch: embed_scatter_scratch_ints(n0 + n1, V) ints
 hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, const float* dout0, int n0, const int32_t* ids1,
                               const float* dout1, int n1, int D, int V, int32_t* scratch);
-inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 + n; }
+inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 + n + (n / 32 + V + 1); }
 // dst[i,:] = src[idx[i],:] for i < *n_dev
 hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);
 // dst[r,:] = rank[r] >= 0 ? src[rank[r],:] : 0   for r < rows

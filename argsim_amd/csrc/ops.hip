@@ -167,16 +167,26 @@ struct Scatter2 {
     int32_t* off;      // [V+1] first list slot of an id
     int32_t* segoff;   // [V+1] first segment of an id
     int32_t* list;     // [n0+n1] token numbers grouped by id (token t >= n0 is row t - n0 of the second source)
+    int32_t* segid;    // [<= (n0+n1)/kScatterSeg + V] id of every segment
 };
 __device__ __forceinline__ int scatter_id(const Scatter2& a, int t)
 {
     int id = t < a.n0 ? a.ids0[t] : a.ids1[t - a.n0];
     return id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
 }
+// Counting and list filling go through a per-workgroup histogram in LDS: a Zipf batch puts a tenth of its tokens on ONE
+// id, and same-address global atomics serialise at ~18 ns each (62 us for 33 K tokens, measured); in LDS the hot bin costs a
+// few cycles per token and the global counter sees one add per workgroup.  kScatterLdsV bins fit the static LDS limit.
+constexpr int kScatterLdsV = 12288, kScatterTok = 1024;      // tokens per workgroup (4 per thread)
 __global__ __launch_bounds__(256) void scatter_hist_kernel(Scatter2 a)
 {
-    const int n = a.n0 + a.n1;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) atomicAdd(a.cnt + scatter_id(a, t), 1);
+    __shared__ int lc[kScatterLdsV];
+    const int n = a.n0 + a.n1, tid = threadIdx.x, t0 = blockIdx.x * kScatterTok;
+    for (int i = tid; i < a.V; i += 256) lc[i] = 0;
+    __syncthreads();
+    for (int t = t0 + tid; t < min(n, t0 + kScatterTok); t += 256) atomicAdd(&lc[scatter_id(a, t)], 1);
+    __syncthreads();
+    for (int i = tid; i < a.V; i += 256) { const int c = lc[i]; if (c) atomicAdd(a.cnt + i, c); }
 }
 __global__ __launch_bounds__(1024) void scatter_scan_kernel(Scatter2 a)        // one workgroup: V is a few thousand
 {
@@ -196,35 +206,55 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(Scatter2 a)        /
     for (int i = beg; i < end; ++i) {
         const int c = a.cnt[i];
         a.off[i] = rt; a.segoff[i] = rs;
-        rt += c; rs += (c + kScatterSeg - 1) / kScatterSeg;
+        rt += c;
+        for (int k = (c + kScatterSeg - 1) / kScatterSeg; k > 0; --k) a.segid[rs++] = i;
     }
     if (tid == 1023) { a.off[a.V] = s_tok[1023]; a.segoff[a.V] = s_seg[1023]; }
 }
 __global__ __launch_bounds__(256) void scatter_fill_kernel(Scatter2 a)
 {
-    const int n = a.n0 + a.n1;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        const int id = scatter_id(a, t);
-        a.list[a.off[id] + atomicAdd(a.cur + id, 1)] = t;
+    __shared__ int lc[kScatterLdsV];
+    const int n = a.n0 + a.n1, tid = threadIdx.x, t0 = blockIdx.x * kScatterTok;
+    for (int i = tid; i < a.V; i += 256) lc[i] = 0;
+    __syncthreads();
+    int id[kScatterTok / 256], rk[kScatterTok / 256];          // rank of each of this thread's tokens inside the workgroup's share of its id
+#pragma unroll
+    for (int q = 0; q < kScatterTok / 256; ++q) {
+        const int t = t0 + tid + 256 * q;
+        id[q] = -1; rk[q] = 0;
+        if (t < n) { id[q] = scatter_id(a, t); rk[q] = atomicAdd(&lc[id[q]], 1); }
     }
+    __syncthreads();
+    for (int i = tid; i < a.V; i += 256) { const int c = lc[i]; if (c) lc[i] = atomicAdd(a.cur + i, c); }     // the share's first slot
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kScatterTok / 256; ++q)
+        if (id[q] >= 0) a.list[a.off[id[q]] + lc[id[q]] + rk[q]] = t0 + tid + 256 * q;
 }
 __global__ __launch_bounds__(256) void scatter_reduce_kernel(Scatter2 a)
 {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, nseg = a.segoff[a.V], D = a.D;
     for (int sg = blockIdx.x * wpb + (threadIdx.x >> 6); sg < nseg; sg += gridDim.x * wpb) {
-        int lo = 0, hi = a.V;                        // the id whose segment range holds sg: last i with segoff[i] <= sg
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.segoff[mid] <= sg) lo = mid; else hi = mid; }
-        const int id = lo, first = a.segoff[id], cnt = a.off[id + 1] - a.off[id];
+        const int id = a.segid[sg], first = a.segoff[id], cnt = a.off[id + 1] - a.off[id];
         const int beg = a.off[id] + (sg - first) * kScatterSeg, end = min(a.off[id] + cnt, beg + kScatterSeg);
         float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};     // D <= 512: two 16-byte pieces per lane
-        for (int i = beg; i < end; ++i) {
-            const int t = a.list[i];
-            const float* s = t < a.n0 ? a.dout0 + (size_t)t * D : a.dout1 + (size_t)(t - a.n0) * D;
+        for (int i = beg; i < end; i += 4) {          // four rows in flight: the token numbers first, then their rows
+            int t[4]; float4 v[4][2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int c = 4 * lane + 256 * q;
-                if (c < D) { const float4 v = *reinterpret_cast<const float4*>(s + c); acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w; }
+            for (int u = 0; u < 4; ++u) t[u] = a.list[min(i + u, end - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* s = t[u] < a.n0 ? a.dout0 + (size_t)t[u] * D : a.dout1 + (size_t)(t[u] - a.n0) * D;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c = 4 * lane + 256 * q;
+                    v[u][q] = (c < D && i + u < end) ? *reinterpret_cast<const float4*>(s + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { acc[q].x += v[u][q].x; acc[q].y += v[u][q].y; acc[q].z += v[u][q].z; acc[q].w += v[u][q].w; }
         }
         float* d = a.dE + (size_t)id * D;
         const bool alone = cnt <= kScatterSeg;       // the only segment of its id: no other wave touches this row
@@ -242,16 +272,33 @@ __global__ __launch_bounds__(256) void scatter_reduce_kernel(Scatter2 a)
         }
     }
 }
+// fallback (vocabularies beyond the LDS histogram, rows longer than two pieces per lane): one float atomic per element
+__global__ __launch_bounds__(256) void embed_scatter_atomic_kernel(float* __restrict__ dE, const int32_t* __restrict__ ids,
+                                                                   const float* __restrict__ dout, int n, int D, int V)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const float* s = dout + (size_t)row * D;
+        float* d = dE + (size_t)id * D;
+        for (int c = lane; c < D; c += 64) atomicAdd(d + c, s[c]);
+    }
+}
 hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, const float* dout0, int n0, const int32_t* ids1,
                               const float* dout1, int n1, int D, int V, int32_t* scratch)
 {
     const int n = n0 + n1;
     if (n <= 0) return hipSuccess;
-    if (D > 512 || (D & 3)) return hipErrorInvalidValue;
-    Scatter2 a{dE, ids0, dout0, n0, ids1, dout1, n1, D, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1, scratch + 4 * V + 2};
+    if (D > 512 || (D & 3) || V > kScatterLdsV) {
+        if (n0 > 0) hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(std::min((n0 + 3) / 4, 4096)), dim3(256), 0, st, dE, ids0, dout0, n0, D, V);
+        if (n1 > 0) hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(std::min((n1 + 3) / 4, 4096)), dim3(256), 0, st, dE, ids1, dout1, n1, D, V);
+        return hipGetLastError();
+    }
+    Scatter2 a{dE, ids0, dout0, n0, ids1, dout1, n1, D, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1, scratch + 4 * V + 2, scratch + 4 * V + 2 + n};
     hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * (size_t)V, st);
     if (e != hipSuccess) return e;
-    const int blocks = std::min((n + 255) / 256, 1024);
+    const int blocks = (n + kScatterTok - 1) / kScatterTok;
     hipLaunchKernelGGL(scatter_hist_kernel, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(scatter_fill_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -9,6 +9,10 @@ CASES = {
     'mid':   (dict(dim_tgt=256, dim_emb=64, dim_rep=32, rnn_layers=3), 8, 16, [16, 2, 9, 16, 1, 5, 12, 7]),
     'wide':  (dict(dim_tgt=512, dim_emb=256, dim_rep=64, rnn_layers=2), 20, 9, None),
     'full2': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 2, 64, [64, 23]),
+    # five word ids for 288 tokens: every id owns several 32-row segments of the grouped embedding-gradient scatter
+    'hot':   (dict(dim_tgt=8, dim_emb=16, dim_rep=8, rnn_layers=1), 24, 12, None),
+    # a vocabulary beyond the scatter's LDS histogram: the per-element atomic fallback
+    'bigv':  (dict(dim_tgt=12800, dim_emb=16, dim_rep=8, rnn_layers=1), 4, 6, [6, 2, 4, 1]),
 }
 # production geometry (D = 512, V = 8192, B = 64: one full 64-row block per GRU workgroup, so the LDS-weight team
 # kernels, the fast-staging and split-K GEMM paths run).  Too large for the live float64 oracle inside a test:
