@@ -452,6 +452,94 @@ hipError_t latent_bwd(hipStream_t st, const float* dz, const float* mu, const fl
 // pass 2 (optional) overwrites the row with (softmax - onehot) * scale.
 // REG: V <= 8192 -- the row (<= 32 floats per thread) is read ONCE and stays in registers between the two passes
 // (1 read + 1 write of the logits instead of 2 + 1: this kernel is HBM-bound)
+// The V <= 8192 form (row in registers).  It was VALU-bound, not HBM-bound: the online max / sum-exp update evaluated two
+// libm expf per element and the gradient pass a third (~80 instructions per element, 214 us for 545 MB).  Now: pass A finds
+// the row maximum and first argmax (no exponential), pass B replaces every kept logit by exp2((x - m) log2 e) -- ONE v_exp_f32
+// per element -- and sums, pass C writes kept * scale / sum - onehot * scale.  exp2 of a non-positive argument on the hardware
+// unit is accurate to 1 ulp; the loss uses m + log(sum).
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__global__ __launch_bounds__(256) void softmax_ce_reg_kernel(CeArgs a)
+{
+    __shared__ float s_m[4], s_s[4]; __shared__ int s_bi[4];
+    __shared__ float s_acc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(a.n_max, *a.n_dev);
+    const float scale = a.inv_n > 0.f ? a.inv_n : 1.f / (float)max(n, 1);
+    if (tid == 0) s_acc = 0.f;
+    __syncthreads();
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        float* x = a.logits + (size_t)row * a.V;
+        const int label = a.gold[a.cidx[row]];
+        float4 keep[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = tid * 4 + 1024 * q;
+            keep[q] = c < a.V ? *reinterpret_cast<const float4*>(x + c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+        const float xl = x[label];                       // (before anything overwrites the row)
+        // pass A: maximum and its first position
+        float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = tid * 4 + 1024 * q;
+            const float e[4] = {keep[q].x, keep[q].y, keep[q].z, keep[q].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (e[k] > bv) { bv = e[k]; bi = c + k; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_down(bv, o, 64); const int oi = __shfl_down(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();                                 // (s_* of the previous row have been read)
+        if (lane == 0) { s_m[wave] = bv; s_bi[wave] = bi; }
+        __syncthreads();
+        bv = s_m[0]; bi = s_bi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (s_m[w] > bv || (s_m[w] == bv && s_bi[w] < bi)) { bv = s_m[w]; bi = s_bi[w]; }
+        const float m = bv;
+        // pass B: one exponential per element, kept
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            keep[q].x = exp_fast(keep[q].x - m); keep[q].y = exp_fast(keep[q].y - m);
+            keep[q].z = exp_fast(keep[q].z - m); keep[q].w = exp_fast(keep[q].w - m);
+            s += (keep[q].x + keep[q].y) + (keep[q].z + keep[q].w);
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) s_s[wave] = s;
+        __syncthreads();
+        s = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+        if (tid == 0) {
+            const float loss = m + logf(s) - xl;
+            if (a.loss_samp) a.loss_samp[row] = loss;
+            if (a.errt_samp) a.errt_samp[row] = (label != bi) ? 1.f : 0.f;
+            if (a.pred) a.pred[row] = bi;
+            s_acc += loss;
+        }
+        if (a.write_grad) {
+            const float g = scale / s;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = tid * 4 + 1024 * q;
+                if (c >= a.V) break;
+                float e[4] = {keep[q].x, keep[q].y, keep[q].z, keep[q].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = e[k] * g - ((c + k) == label ? scale : 0.f);
+                if (a.grad16) {      // bf16 mode: the GEMM operand panel itself (RNE, what the conversion pass would have written)
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 lo = {e[0], e[1]}, hi = {e[2], e[3]};
+                    const uint2 pk = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf2)));
+                    *reinterpret_cast<uint2*>(a.grad16 + (size_t)row * a.V + c) = pk;
+                } else
+                *reinterpret_cast<float4*>(x + c) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && a.loss_acc) atomicAdd(a.loss_acc, s_acc);
+}
+
 template <bool REG>
 __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
 {
@@ -543,7 +631,7 @@ hipError_t softmax_ce(hipStream_t st, const CeArgs& a)
 {
     if (a.n_max <= 0) return hipSuccess;
     if (a.V & 3) return hipErrorInvalidValue;
-    if (a.V <= 8192) hipLaunchKernelGGL(softmax_ce_kernel<true>, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    if (a.V <= 8192) hipLaunchKernelGGL(softmax_ce_reg_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
     else             hipLaunchKernelGGL(softmax_ce_kernel<false>, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -577,24 +665,36 @@ hipError_t argmax_rows(hipStream_t st, const float* logits, int32_t* pred, int n
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
-// block = 64 columns x 4 row lanes; grid.y chunks of 1024 rows; float atomics into out (+=).
+// block = 64 columns x 4 row lanes; grid.y chunks of `chunk` rows, sized so that ~1024 workgroups share the rows (with
+// 1024-row chunks the 16 640 x 512 sum ran on 136 workgroups of 256 dependent loads each: 62 us for 34 MB); float atomics
+// into out (+=).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
-                                                     float* __restrict__ out, const int32_t* __restrict__ m_dev)
+                                                     float* __restrict__ out, const int32_t* __restrict__ m_dev, int chunk)
 {
     __shared__ float sh[4][64];
     if (m_dev) M = min(M, *m_dev);
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * 1024, r1 = min(M, r0 + 1024);
-    float s = 0.f;
-    if (c < N) for (int r = r0 + rl; r < r1; r += 4) s += X[(size_t)r * ldx + c];
-    sh[rl][threadIdx.x & 63] = s;
+    const int r0 = blockIdx.y * chunk, r1 = min(M, r0 + chunk);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < N) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {         // four independent loads in flight per thread
+            s0 += X[(size_t)r * ldx + c]; s1 += X[(size_t)(r + 4) * ldx + c];
+            s2 += X[(size_t)(r + 8) * ldx + c]; s3 += X[(size_t)(r + 12) * ldx + c];
+        }
+        for (; r < r1; r += 4) s0 += X[(size_t)r * ldx + c];
+    }
+    sh[rl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && c < N && r0 < r1) atomicAdd(out + c, (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
 }
 hipError_t colsum(hipStream_t st, const float* X, int M, int N, int ldx, float* out, const int32_t* m_dev)
 {
     if (M <= 0 || N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + 1023) / 1024), dim3(256), 0, st, X, M, N, ldx, out, m_dev);
+    const int gx = (N + 63) / 64, want = std::max(1, 1024 / gx);
+    int chunk = std::max(16, (M + want - 1) / want);
+    chunk = (chunk + 3) & ~3;
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, (M + chunk - 1) / chunk), dim3(256), 0, st, X, M, N, ldx, out, m_dev, chunk);
     return hipGetLastError();
 }
 
