@@ -114,6 +114,9 @@ hipError_t embed_gather(hipStream_t st, const float* E, const int32_t* ids, floa
 // dE[ids0[t]] += dout0[t], dE[ids1[t]] += dout1[t]; scratch: embed_scatter_scratch_ints(n0 + n1, V) ints
 hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, const float* dout0, int n0, const int32_t* ids1,
                               const float* dout1, int n1, int D, int V, int32_t* scratch);
+// dst[t,:] = src[ids[t],:] (rows of W floats);   dst (V x W) = sum over t of src[t,:] into row ids[t] (dst zero-filled here)
+hipError_t rows_gather_ids(hipStream_t st, float* dst, const float* src, const int32_t* ids, int n, int W, int V);
+hipError_t rows_scatter_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch);
 inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 + n + (n / 32 + V + 1); }
 // dst[i,:] = src[idx[i],:] for i < *n_dev
 hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);

@@ -48,6 +48,7 @@ struct avae_ctx {
     std::vector<int> hook_pending;     // buckets complete but not yet announced (see hook_flush)
     int persistent = 1;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
@@ -114,7 +115,7 @@ struct Ws {
     // ints
     int32_t *src_tm, *lens_src, *lens_tgt, *lead, *gold, *rank, *cidx, *ntok, *pred;
     // forward
-    float *emb_src, *emb_tgt;
+    float *emb_src, *emb_tgt, *ew, *dew;
     std::vector<float*> e_gi, e_hs, e_sv[2], e_hp[2];
     std::vector<float*> d_gi, d_hd, d_sv, d_hp;
     float *hpick, *mu, *lv, *z, *eps, *kld, *h0;
@@ -145,6 +146,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.lead = b.take<int32_t>(rt); w.gold = b.take<int32_t>(rt); w.rank = b.take<int32_t>(rt);
     w.cidx = b.take<int32_t>(rt); w.ntok = b.take<int32_t>(4 + kPrepChunks); w.pred = b.take<int32_t>(rt);      // (ntok[4..]: prep_ids' chunk counts)
     w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
+    w.ew = b.take<float>((size_t)V * 6 * D);      // W E over the table (use_table): (V, 6D) encoder layer 1, then (V, 3D) decoder layer 1
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
     w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
@@ -186,6 +188,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.dgi_e = b.take<float>(rs * 6 * D); w.dgh_e = b.take<float>(rs * 6 * D);
         w.demb_src = b.take<float>(rs * D); w.demb_tgt = b.take<float>(rt * D);
         w.scat = b.take<int32_t>(embed_scatter_scratch_ints(rs + rt, V));
+        w.dew = b.take<float>((size_t)V * 6 * D);  // gate gradients of a table-fed layer summed by id
     }
 }
 
@@ -376,15 +379,26 @@ Sched schedule(const avae_ctx* h)
     return s;
 }
 
+// A layer whose input is an embedding row (encoder layer 1: E[src]; decoder layer 1: E[lead]) computes W E[id].  With more
+// tokens than vocabulary entries the projection is taken over the table once (V rows instead of `rows`) and gathered by
+// id; the backward sums the per-token gate gradients by id (rows_scatter_sum) and runs dW = (sum)^T E and
+// dE += (sum) W over V rows.  The same products grouped by id: exact algebra, a different summation order in the backward.
+static bool use_table(const avae_ctx* h, int rows) { return h->table_l1 && rows >= h->cfg.dim_tgt; }
+
 // -------------------------------------------------------------------------------- forward pieces
 int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 {
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
     const int rs = Ss * B;
-    AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.src_tm, w.emb_src, rs, D, V));
+    const bool table = use_table(h, rs);
+    if (!table) AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.src_tm, w.emb_src, rs, D, V));
     const float* x = w.emb_src; int In = D;
     for (int i = 0; i < L; ++i) {
         const GruP& p = h->enc[i];
+        if (i == 0 && table) {
+            AV_TRY(gemm(h, false, false, h->P + h->oE, D, h->P + p.W, D, w.ew, 6 * D, V, 6 * D, D, 1.f, h->P + p.bW));
+            AV_CHECK(rows_gather_ids(h->stream, w.e_gi[0], w.ew, w.src_tm, rs, 6 * D, V));
+        } else
         AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, 6 * D, In, 1.f, h->P + p.bW));
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
@@ -421,13 +435,18 @@ int run_latent(avae_ctx* h, Ws& w, int B, bool train, uint64_t seed, const float
 }
 
 // decoder GRU stack over T steps from per-layer initial states (state stride: layer * B * D; 0 = shared h0)
-int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int64_t state_stride, bool save)
+int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int64_t state_stride, bool save, const int32_t* ids0 = nullptr)
 {
     const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
     const int rt = T * B;
     const float* x = w.emb_tgt;
     for (int i = 0; i < L; ++i) {
         const GruP& p = h->dec[i];
+        if (i == 0 && ids0) {       // (ids0: the layer input is E[ids0], not yet gathered -- use_table decided by the caller)
+            const int V = h->cfg.dim_tgt;
+            AV_TRY(gemm(h, false, false, h->P + h->oE, D, h->P + p.W, D, w.ew, 3 * D, V, 3 * D, D, 1.f, h->P + p.bW));
+            AV_CHECK(rows_gather_ids(h->stream, w.d_gi[0], w.ew, ids0, rt, 3 * D, V));
+        } else
         AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
@@ -462,8 +481,11 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
     AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
-    AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.lead, w.emb_tgt, rt, D, V));
-    AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train));
+    if (use_table(h, rt)) AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train, w.lead));
+    else {
+        AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.lead, w.emb_tgt, rt, D, V));
+        AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train));
+    }
     AV_CHECK(rows_gather(h->stream, w.hc, w.d_hd[L - 1], w.cidx, w.ntok, rt, D));
     AV_TRY(gemm(h, false, true, w.hc, D, h->P + h->oKout, D, w.ho, D, rt, D, D, 1.f, h->P + h->oBout, 0, 0, w.ntok, 1));
     AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 0, w.ntok, 1));
@@ -550,6 +572,13 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
+        if (i == 0 && use_table(h, rt)) {
+            // table-fed layer: gate gradients summed by id, then dW = (sum)^T E and dE += (sum) W over V rows
+            AV_CHECK(rows_scatter_sum(st, w.dew, w.lead, w.dgi_d, rt, 3 * D, V, w.scat));
+            AV_TRY(gemm_tn_grad(h, w.dew, 3 * D, P + h->oE, D, G + p.W, D, 3 * D, D, V));
+            AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
+            AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, G + h->oE, D, V, D, 3 * D, 1.f, nullptr, 1));
+        } else {
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         {   // dW = dgi^T x and dR = dgh^T h_prev: same shape over the same rows, one launch
             const Pair dR{w.dgh_d, w.d_hp[i], G + p.R, nullptr};
@@ -557,6 +586,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         }
         float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
         AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
+        }
         cur ^= 1;
         fire_hook(h, 1 + (L - 1 - i));
     }
@@ -582,6 +612,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
 
     // encoder stack
     cur = 0;
+    bool emb_done = false;
     for (int i = L - 1; i >= 0; --i) {
         const GruP& p = h->enc[i];
         const int In = i == 0 ? D : 2 * D;
@@ -600,21 +631,35 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         { Timed t(h, 2, 2.0 * 2 * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
+        const bool table = i == 0 && use_table(h, rs);
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
+        if (table) {
+            // table-fed layer (use_table).  Its contribution completes the embedding gradient, so that bucket is announced
+            // FIRST and its all-reduce runs beside the two weight-gradient GEMMs below; this layer's own bucket ends backward.
+            AV_CHECK(rows_scatter_sum(st, w.dew, w.src_tm, w.dgi_e, rs, 6 * D, V, w.scat));
+            AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, G + h->oE, D, V, D, 6 * D, 1.f, nullptr, 1));
+            AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, 0, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
+            fire_hook(h, 2 + 2 * L);
+            hook_flush(h);
+            emb_done = true;
+            AV_TRY(gemm_tn_grad(h, w.dew, 6 * D, P + h->oE, D, G + p.W, D, 6 * D, D, V));
+        } else
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         {   // dR of the two directions: same shape, one launch
             const Pair bwd{w.dgh_e + 3 * D, w.e_hp[1][i], G + p.R + (int64_t)3 * D * D, nullptr};
             AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, nullptr, &bwd));
         }
         float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
+        if (!table)
         AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
         fire_hook(h, 2 + L + (L - 1 - i));
         if (i == 0) hook_flush(h);         // no persistent launch follows: announce now, beside the embedding scatter-adds
     }
-    // embedding: gather gradients on top of the logits term
-    AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, rt, D, V, w.scat));
-    fire_hook(h, 2 + 2 * L);
+    if (!emb_done) {    // embedding: gather gradients on top of the logits term
+        AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
+        fire_hook(h, 2 + 2 * L);
+    }
     hook_flush(h);
     return 0;
 }
@@ -831,6 +876,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_stagger")) { h->gru_stagger = value; return 0; }
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
+    if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");

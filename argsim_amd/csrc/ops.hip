@@ -306,6 +306,77 @@ hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, co
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- rows of a table by word id, and the transpose of that
+// A layer whose input is an embedding row computes W E[id]: with more tokens than vocabulary entries the projection is
+// taken over the TABLE once (E W', V rows) and the per-token result is a row gather of it (rows_gather_ids); in the
+// backward the per-token gradients are summed by id first (rows_scatter_sum, the grouped scatter above on wide rows) and the
+// two weight-side products run over V rows instead of over every token.  Exact algebra: the same products, grouped by id.
+__global__ __launch_bounds__(256) void rows_gather_ids_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                              const int32_t* __restrict__ ids, int n, int W, int V)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const float4* s = reinterpret_cast<const float4*>(src + (size_t)id * W);
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)row * W);
+        for (int c = lane; c < W / 4; c += 64) d[c] = s[c];
+    }
+}
+hipError_t rows_gather_ids(hipStream_t st, float* dst, const float* src, const int32_t* ids, int n, int W, int V)
+{
+    if (n <= 0) return hipSuccess;
+    if (W & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_gather_ids_kernel, dim3(std::min((n + 3) / 4, 8192)), dim3(256), 0, st, dst, src, ids, n, W, V);
+    return hipGetLastError();
+}
+// work item = (segment, block of 256 columns); dst was zero-filled: a single-segment id stores, a hot id's segments add
+__global__ __launch_bounds__(256) void scatter_reduce_wide_kernel(Scatter2 a, float* __restrict__ dst, const float* __restrict__ src, int W)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, nseg = a.segoff[a.V], ncb = (W + 255) / 256;
+    const long long items = (long long)nseg * ncb;
+    for (long long it = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); it < items; it += (long long)gridDim.x * wpb) {
+        const int sg = (int)(it / ncb), c = (int)(it - (long long)sg * ncb) * 256 + 4 * lane;
+        const int id = a.segid[sg], first = a.segoff[id], cnt = a.off[id + 1] - a.off[id];
+        const int beg = a.off[id] + (sg - first) * kScatterSeg, end = min(a.off[id] + cnt, beg + kScatterSeg);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = beg; i < end; i += 4) {
+            int t[4]; float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = a.list[min(i + u, end - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = (c < W && i + u < end) ? *reinterpret_cast<const float4*>(src + (size_t)t[u] * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        if (c >= W) continue;
+        float* d = dst + (size_t)id * W + c;
+        if (cnt <= kScatterSeg) *reinterpret_cast<float4*>(d) = acc;
+        else { atomicAdd(d, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w); }
+    }
+}
+hipError_t rows_scatter_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch)
+{
+    if (W & 3) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(dst, 0, sizeof(float) * (size_t)V * W, st);
+    if (e != hipSuccess || n <= 0) return e;
+    if (V > kScatterLdsV) {
+        hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(std::min((n + 3) / 4, 4096)), dim3(256), 0, st, dst, ids, src, n, W, V);
+        return hipGetLastError();
+    }
+    Scatter2 a{dst, ids, src, n, nullptr, nullptr, 0, W, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1, scratch + 4 * V + 2, scratch + 4 * V + 2 + n};
+    e = hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * (size_t)V, st);
+    if (e != hipSuccess) return e;
+    const int blocks = (n + kScatterTok - 1) / kScatterTok;
+    hipLaunchKernelGGL(scatter_hist_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(scatter_fill_kernel, dim3(blocks), dim3(256), 0, st, a);
+    const long long items = ((long long)n / 8 + V) * ((W + 255) / 256);
+    hipLaunchKernelGGL(scatter_reduce_wide_kernel, dim3((unsigned)std::min<long long>((items + 3) / 4, 8192)), dim3(256), 0, st, a, dst, src, W);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- compaction (tf.boolean_mask, model.py:161)
 __global__ __launch_bounds__(256) void rows_gather_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                           const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev,

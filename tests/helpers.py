@@ -11,6 +11,8 @@ CASES = {
     'full2': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 2, 64, [64, 23]),
     # five word ids for 288 tokens: every id owns several 32-row segments of the grouped embedding-gradient scatter
     'hot':   (dict(dim_tgt=8, dim_emb=16, dim_rep=8, rnn_layers=1), 24, 12, None),
+    # more tokens than vocabulary entries: the layers fed by embedding rows project the table and gather / scatter by id
+    'tab':   (dict(dim_tgt=64, dim_emb=64, dim_rep=16, rnn_layers=2), 12, 10, [10, 3, 7, 10, 1, 5, 9, 2, 10, 6, 4, 8]),
     # a vocabulary beyond the scatter's LDS histogram: the per-element atomic fallback
     'bigv':  (dict(dim_tgt=12800, dim_emb=16, dim_rep=8, rnn_layers=1), 4, 6, [6, 2, 4, 1]),
 }
