@@ -114,9 +114,16 @@ hipError_t embed_gather(hipStream_t st, const float* E, const int32_t* ids, floa
 // dE[ids0[t]] += dout0[t], dE[ids1[t]] += dout1[t]; scratch: embed_scatter_scratch_ints(n0 + n1, V) ints
 hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, const float* dout0, int n0, const int32_t* ids1,
                               const float* dout1, int n1, int D, int V, int32_t* scratch);
-// dst[t,:] = src[ids[t],:] (rows of W floats);   dst (V x W) = sum over t of src[t,:] into row ids[t] (dst zero-filled here)
-hipError_t rows_gather_ids(hipStream_t st, float* dst, const float* src, const int32_t* ids, int n, int W, int V);
-hipError_t rows_scatter_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch);
+// token groups of an id source (ops.hip "token groups"): built once per step, used by the forward gather and the backward sums
+bool id_groups_supported(int V);
+inline size_t id_groups_ints(size_t n, size_t V) { return 4 * V + 2 + n + (n / 32 + V + 1) + 2 * V + 4; }
+hipError_t id_groups_build(hipStream_t st, const int32_t* ids, int n, int V, int32_t* scratch, bool lists);
+const int32_t* id_groups_rank(int32_t* scratch, int n, int V);     // [V]  index among the present ids, -1 absent
+const int32_t* id_groups_uid(int32_t* scratch, int n, int V);      // [V]  present ids, ascending
+const int32_t* id_groups_count(int32_t* scratch, int n, int V);    // [1]  how many
+hipError_t rows_gather_ranked(hipStream_t st, float* dst, const float* src, const int32_t* ids, const int32_t* rank, int n, int W, int V);
+hipError_t rows_group_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch);
+hipError_t rows_add_indexed(hipStream_t st, float* dst, const float* src, const int32_t* uid, const int32_t* nuniq, int n_max, int D);
 inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 + n + (n / 32 + V + 1); }
 // dst[i,:] = src[idx[i],:] for i < *n_dev
 hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);

@@ -125,6 +125,7 @@ struct Ws {
     float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
     int32_t* scat;                        // embed_scatter_add2's token lists
+    int32_t *grp_src, *grp_tgt;           // id_groups_build scratch of the two id sources (use_table)
     float* xbuf; size_t xbuf_floats;      // exchange scratch of the GRU team kernels (GruArgs::xbuf)
 };
 
@@ -146,7 +147,8 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.lead = b.take<int32_t>(rt); w.gold = b.take<int32_t>(rt); w.rank = b.take<int32_t>(rt);
     w.cidx = b.take<int32_t>(rt); w.ntok = b.take<int32_t>(4 + kPrepChunks); w.pred = b.take<int32_t>(rt);      // (ntok[4..]: prep_ids' chunk counts)
     w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
-    w.ew = b.take<float>((size_t)V * 6 * D);      // W E over the table (use_table): (V, 6D) encoder layer 1, then (V, 3D) decoder layer 1
+    w.ew = b.take<float>((size_t)V * 6 * D);      // W E over the present ids (use_table): (U, 6D) encoder layer 1, then (U, 3D) decoder layer 1
+    w.grp_src = b.take<int32_t>(id_groups_ints(rs, V)); w.grp_tgt = b.take<int32_t>(id_groups_ints(rt, V));     // token groups by id
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
     w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
@@ -380,10 +382,12 @@ Sched schedule(const avae_ctx* h)
 }
 
 // A layer whose input is an embedding row (encoder layer 1: E[src]; decoder layer 1: E[lead]) computes W E[id].  With more
-// tokens than vocabulary entries the projection is taken over the table once (V rows instead of `rows`) and gathered by
-// id; the backward sums the per-token gate gradients by id (rows_scatter_sum) and runs dW = (sum)^T E and
-// dE += (sum) W over V rows.  The same products grouped by id: exact algebra, a different summation order in the backward.
-static bool use_table(const avae_ctx* h, int rows) { return h->table_l1 && rows >= h->cfg.dim_tgt; }
+// tokens than vocabulary entries the projection is taken once over the U <= V ids present in the batch (their E rows
+// gathered, one GEMM with a device-side row count) and gathered by id; the backward sums the per-token gate gradients by id
+// (rows_group_sum) and runs dW = (sum)^T E_present and dE[present] += (sum) W over U rows.  The same products grouped by id:
+// exact algebra, a different summation order in the backward.  The compact E rows live in emb_src / emb_tgt (unused
+// otherwise in this mode), the per-id gradient of E in demb_src / demb_tgt.
+static bool use_table(const avae_ctx* h, int rows) { return h->table_l1 && rows >= h->cfg.dim_tgt && id_groups_supported(h->cfg.dim_tgt); }
 
 // -------------------------------------------------------------------------------- forward pieces
 int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
@@ -396,8 +400,11 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
     for (int i = 0; i < L; ++i) {
         const GruP& p = h->enc[i];
         if (i == 0 && table) {
-            AV_TRY(gemm(h, false, false, h->P + h->oE, D, h->P + p.W, D, w.ew, 6 * D, V, 6 * D, D, 1.f, h->P + p.bW));
-            AV_CHECK(rows_gather_ids(h->stream, w.e_gi[0], w.ew, w.src_tm, rs, 6 * D, V));
+            const int32_t* cnt = id_groups_count(w.grp_src, rs, V);
+            AV_CHECK(id_groups_build(h->stream, w.src_tm, rs, V, w.grp_src, save));
+            AV_CHECK(rows_gather(h->stream, w.emb_src, h->P + h->oE, id_groups_uid(w.grp_src, rs, V), cnt, std::min(V, rs), D));
+            AV_TRY(gemm(h, false, false, w.emb_src, D, h->P + p.W, D, w.ew, 6 * D, std::min(V, rs), 6 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
+            AV_CHECK(rows_gather_ranked(h->stream, w.e_gi[0], w.ew, w.src_tm, id_groups_rank(w.grp_src, rs, V), rs, 6 * D, V));
         } else
         AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, 6 * D, In, 1.f, h->P + p.bW));
         GruArgs a{};
@@ -444,8 +451,11 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         const GruP& p = h->dec[i];
         if (i == 0 && ids0) {       // (ids0: the layer input is E[ids0], not yet gathered -- use_table decided by the caller)
             const int V = h->cfg.dim_tgt;
-            AV_TRY(gemm(h, false, false, h->P + h->oE, D, h->P + p.W, D, w.ew, 3 * D, V, 3 * D, D, 1.f, h->P + p.bW));
-            AV_CHECK(rows_gather_ids(h->stream, w.d_gi[0], w.ew, ids0, rt, 3 * D, V));
+            const int32_t* cnt = id_groups_count(w.grp_tgt, rt, V);
+            AV_CHECK(id_groups_build(h->stream, ids0, rt, V, w.grp_tgt, save));
+            AV_CHECK(rows_gather(h->stream, w.emb_tgt, h->P + h->oE, id_groups_uid(w.grp_tgt, rt, V), cnt, std::min(V, rt), D));
+            AV_TRY(gemm(h, false, false, w.emb_tgt, D, h->P + p.W, D, w.ew, 3 * D, std::min(V, rt), 3 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
+            AV_CHECK(rows_gather_ranked(h->stream, w.d_gi[0], w.ew, ids0, id_groups_rank(w.grp_tgt, rt, V), rt, 3 * D, V));
         } else
         AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
         GruArgs a{};
@@ -574,10 +584,12 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         hook_flush(h);
         if (i == 0 && use_table(h, rt)) {
             // table-fed layer: gate gradients summed by id, then dW = (sum)^T E and dE += (sum) W over V rows
-            AV_CHECK(rows_scatter_sum(st, w.dew, w.lead, w.dgi_d, rt, 3 * D, V, w.scat));
-            AV_TRY(gemm_tn_grad(h, w.dew, 3 * D, P + h->oE, D, G + p.W, D, 3 * D, D, V));
+            const int32_t* cnt = id_groups_count(w.grp_tgt, rt, V); const int U = std::min(V, rt);
+            AV_CHECK(rows_group_sum(st, w.dew, w.lead, w.dgi_d, rt, 3 * D, V, w.grp_tgt));
+            AV_TRY(gemm_tn_grad(h, w.dew, 3 * D, w.emb_tgt, D, G + p.W, D, 3 * D, D, U, 1.f, cnt));
             AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
-            AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, G + h->oE, D, V, D, 3 * D, 1.f, nullptr, 1));
+            AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, w.demb_tgt, D, U, D, 3 * D, 1.f, nullptr, 0, 0, cnt, 1));
+            AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
         } else {
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         {   // dW = dgi^T x and dR = dgh^T h_prev: same shape over the same rows, one launch
@@ -636,13 +648,15 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         if (table) {
             // table-fed layer (use_table).  Its contribution completes the embedding gradient, so that bucket is announced
             // FIRST and its all-reduce runs beside the two weight-gradient GEMMs below; this layer's own bucket ends backward.
-            AV_CHECK(rows_scatter_sum(st, w.dew, w.src_tm, w.dgi_e, rs, 6 * D, V, w.scat));
-            AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, G + h->oE, D, V, D, 6 * D, 1.f, nullptr, 1));
+            const int32_t* cnt = id_groups_count(w.grp_src, rs, V); const int U = std::min(V, rs);
+            AV_CHECK(rows_group_sum(st, w.dew, w.src_tm, w.dgi_e, rs, 6 * D, V, w.grp_src));
+            AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, w.demb_src, D, U, D, 6 * D, 1.f, nullptr, 0, 0, cnt, 1));
+            AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_src, id_groups_uid(w.grp_src, rs, V), cnt, U, D));
             AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, 0, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
             fire_hook(h, 2 + 2 * L);
             hook_flush(h);
             emb_done = true;
-            AV_TRY(gemm_tn_grad(h, w.dew, 6 * D, P + h->oE, D, G + p.W, D, 6 * D, D, V));
+            AV_TRY(gemm_tn_grad(h, w.dew, 6 * D, w.emb_src, D, G + p.W, D, 6 * D, D, U, 1.f, cnt));
         } else
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         {   // dR of the two directions: same shape, one launch

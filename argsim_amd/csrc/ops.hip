@@ -168,6 +168,9 @@ struct Scatter2 {
     int32_t* segoff;   // [V+1] first segment of an id
     int32_t* list;     // [n0+n1] token numbers grouped by id (token t >= n0 is row t - n0 of the second source)
     int32_t* segid;    // [<= (n0+n1)/kScatterSeg + V] id of every segment
+    int32_t* rank;     // optional [V]: index of an id among the ids PRESENT in the batch (-1: absent), with
+    int32_t* uid;      //          [V]: the present ids in ascending order, and
+    int32_t* nuniq;    //          [1]: how many there are
 };
 __device__ __forceinline__ int scatter_id(const Scatter2& a, int t)
 {
@@ -190,26 +193,27 @@ __global__ __launch_bounds__(256) void scatter_hist_kernel(Scatter2 a)
 }
 __global__ __launch_bounds__(1024) void scatter_scan_kernel(Scatter2 a)        // one workgroup: V is a few thousand
 {
-    __shared__ int s_tok[1024], s_seg[1024];
+    __shared__ int s_tok[1024], s_seg[1024], s_uni[1024];
     const int tid = threadIdx.x, per = (a.V + 1023) / 1024, beg = min(a.V, tid * per), end = min(a.V, beg + per);
-    int tok = 0, seg = 0;
-    for (int i = beg; i < end; ++i) { const int c = a.cnt[i]; tok += c; seg += (c + kScatterSeg - 1) / kScatterSeg; }
-    s_tok[tid] = tok; s_seg[tid] = seg;
+    int tok = 0, seg = 0, uni = 0;
+    for (int i = beg; i < end; ++i) { const int c = a.cnt[i]; tok += c; seg += (c + kScatterSeg - 1) / kScatterSeg; uni += c > 0; }
+    s_tok[tid] = tok; s_seg[tid] = seg; s_uni[tid] = uni;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        const int vt = tid >= o ? s_tok[tid - o] : 0, vs = tid >= o ? s_seg[tid - o] : 0;
+        const int vt = tid >= o ? s_tok[tid - o] : 0, vs = tid >= o ? s_seg[tid - o] : 0, vu = tid >= o ? s_uni[tid - o] : 0;
         __syncthreads();
-        s_tok[tid] += vt; s_seg[tid] += vs;
+        s_tok[tid] += vt; s_seg[tid] += vs; s_uni[tid] += vu;
         __syncthreads();
     }
-    int rt = s_tok[tid] - tok, rs = s_seg[tid] - seg;
+    int rt = s_tok[tid] - tok, rs = s_seg[tid] - seg, ru = s_uni[tid] - uni;
     for (int i = beg; i < end; ++i) {
         const int c = a.cnt[i];
         a.off[i] = rt; a.segoff[i] = rs;
         rt += c;
         for (int k = (c + kScatterSeg - 1) / kScatterSeg; k > 0; --k) a.segid[rs++] = i;
+        if (a.rank) { a.rank[i] = c > 0 ? ru : -1; if (c > 0) a.uid[ru++] = i; }
     }
-    if (tid == 1023) { a.off[a.V] = s_tok[1023]; a.segoff[a.V] = s_seg[1023]; }
+    if (tid == 1023) { a.off[a.V] = s_tok[1023]; a.segoff[a.V] = s_seg[1023]; if (a.rank) a.nuniq[0] = s_uni[1023]; }
 }
 __global__ __launch_bounds__(256) void scatter_fill_kernel(Scatter2 a)
 {
@@ -295,7 +299,7 @@ hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, co
         if (n1 > 0) hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(std::min((n1 + 3) / 4, 4096)), dim3(256), 0, st, dE, ids1, dout1, n1, D, V);
         return hipGetLastError();
     }
-    Scatter2 a{dE, ids0, dout0, n0, ids1, dout1, n1, D, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1, scratch + 4 * V + 2, scratch + 4 * V + 2 + n};
+    Scatter2 a{dE, ids0, dout0, n0, ids1, dout1, n1, D, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1, scratch + 4 * V + 2, scratch + 4 * V + 2 + n, nullptr, nullptr, nullptr};
     hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * (size_t)V, st);
     if (e != hipSuccess) return e;
     const int blocks = (n + kScatterTok - 1) / kScatterTok;
@@ -306,28 +310,52 @@ hipError_t embed_scatter_add2(hipStream_t st, float* dE, const int32_t* ids0, co
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------- rows of a table by word id, and the transpose of that
-// A layer whose input is an embedding row computes W E[id]: with more tokens than vocabulary entries the projection is
-// taken over the TABLE once (E W', V rows) and the per-token result is a row gather of it (rows_gather_ids); in the
-// backward the per-token gradients are summed by id first (rows_scatter_sum, the grouped scatter above on wide rows) and the
-// two weight-side products run over V rows instead of over every token.  Exact algebra: the same products, grouped by id.
-__global__ __launch_bounds__(256) void rows_gather_ids_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                              const int32_t* __restrict__ ids, int n, int W, int V)
+// ---------------------------------------------------------------- token groups of an id source; rows by id and their transpose
+// A layer whose input is an embedding row computes W E[id].  With more tokens than vocabulary entries the projection is
+// taken once over the ids PRESENT in the batch (U <= V rows: E rows gathered by `uid`, one GEMM with a device-side row
+// count) and the per-token result is a row gather through `rank` (rows_gather_ranked); in the backward the per-token
+// gradients are summed by id first (rows_group_sum: the grouped scatter above on wide rows, written to row rank[id]) and the
+// two weight-side products run over U rows instead of over every token.  Exact algebra: the same products, grouped by id.
+// id_groups_build runs once per step and source (forward); the lists serve the backward of the same step.
+static Scatter2 id_groups_view(const int32_t* ids, int n, int V, int32_t* scratch)
+{
+    int32_t* rank = scratch + 4 * (size_t)V + 2 + n + ((size_t)n / kScatterSeg + V + 1);
+    return Scatter2{nullptr, ids, nullptr, n, nullptr, nullptr, 0, 0, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1,
+                    scratch + 4 * V + 2, scratch + 4 * (size_t)V + 2 + n, rank, rank + V, rank + 2 * (size_t)V};
+}
+const int32_t* id_groups_rank(int32_t* scratch, int n, int V) { return id_groups_view(nullptr, n, V, scratch).rank; }
+const int32_t* id_groups_uid(int32_t* scratch, int n, int V) { return id_groups_view(nullptr, n, V, scratch).uid; }
+const int32_t* id_groups_count(int32_t* scratch, int n, int V) { return id_groups_view(nullptr, n, V, scratch).nuniq; }
+bool id_groups_supported(int V) { return V <= kScatterLdsV; }
+hipError_t id_groups_build(hipStream_t st, const int32_t* ids, int n, int V, int32_t* scratch, bool lists)
+{
+    if (n <= 0 || V > kScatterLdsV) return hipErrorInvalidValue;
+    Scatter2 a = id_groups_view(ids, n, V, scratch);
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * (size_t)V, st);
+    if (e != hipSuccess) return e;
+    const int blocks = (n + kScatterTok - 1) / kScatterTok;
+    hipLaunchKernelGGL(scatter_hist_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    if (lists) hipLaunchKernelGGL(scatter_fill_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void rows_gather_ranked_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                                 const int32_t* __restrict__ ids, const int32_t* __restrict__ rank, int n, int W, int V)
 {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
         int id = ids[row];
         id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-        const float4* s = reinterpret_cast<const float4*>(src + (size_t)id * W);
+        const float4* s = reinterpret_cast<const float4*>(src + (size_t)rank[id] * W);
         float4* d = reinterpret_cast<float4*>(dst + (size_t)row * W);
         for (int c = lane; c < W / 4; c += 64) d[c] = s[c];
     }
 }
-hipError_t rows_gather_ids(hipStream_t st, float* dst, const float* src, const int32_t* ids, int n, int W, int V)
+hipError_t rows_gather_ranked(hipStream_t st, float* dst, const float* src, const int32_t* ids, const int32_t* rank, int n, int W, int V)
 {
     if (n <= 0) return hipSuccess;
     if (W & 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rows_gather_ids_kernel, dim3(std::min((n + 3) / 4, 8192)), dim3(256), 0, st, dst, src, ids, n, W, V);
+    hipLaunchKernelGGL(rows_gather_ranked_kernel, dim3(std::min((n + 3) / 4, 8192)), dim3(256), 0, st, dst, src, ids, rank, n, W, V);
     return hipGetLastError();
 }
 // work item = (segment, block of 256 columns); dst was zero-filled: a single-segment id stores, a hot id's segments add
@@ -351,29 +379,38 @@ __global__ __launch_bounds__(256) void scatter_reduce_wide_kernel(Scatter2 a, fl
             for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
         if (c >= W) continue;
-        float* d = dst + (size_t)id * W + c;
+        float* d = dst + (size_t)a.rank[id] * W + c;
         if (cnt <= kScatterSeg) *reinterpret_cast<float4*>(d) = acc;
         else { atomicAdd(d, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w); }
     }
 }
-hipError_t rows_scatter_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch)
+// dst (rows of the present ids, W floats each; zero-filled here up to min(V, n) rows) = per-id sums of src's rows
+hipError_t rows_group_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch)
 {
-    if (W & 3) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(dst, 0, sizeof(float) * (size_t)V * W, st);
-    if (e != hipSuccess || n <= 0) return e;
-    if (V > kScatterLdsV) {
-        hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(std::min((n + 3) / 4, 4096)), dim3(256), 0, st, dst, ids, src, n, W, V);
-        return hipGetLastError();
-    }
-    Scatter2 a{dst, ids, src, n, nullptr, nullptr, 0, W, V, scratch, scratch + V, scratch + 2 * V, scratch + 3 * V + 1, scratch + 4 * V + 2, scratch + 4 * V + 2 + n};
-    e = hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * (size_t)V, st);
+    if ((W & 3) || n <= 0 || V > kScatterLdsV) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(dst, 0, sizeof(float) * (size_t)std::min(V, n) * W, st);
     if (e != hipSuccess) return e;
-    const int blocks = (n + kScatterTok - 1) / kScatterTok;
-    hipLaunchKernelGGL(scatter_hist_kernel, dim3(blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(scatter_fill_kernel, dim3(blocks), dim3(256), 0, st, a);
+    Scatter2 a = id_groups_view(ids, n, V, scratch);
     const long long items = ((long long)n / 8 + V) * ((W + 255) / 256);
     hipLaunchKernelGGL(scatter_reduce_wide_kernel, dim3((unsigned)std::min<long long>((items + 3) / 4, 8192)), dim3(256), 0, st, a, dst, src, W);
+    return hipGetLastError();
+}
+// dst[uid[r], :] += src[r, :] for r < *nuniq (distinct rows: a plain read-modify-write)
+__global__ __launch_bounds__(256) void rows_add_indexed_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                               const int32_t* __restrict__ uid, const int32_t* __restrict__ nuniq, int n_max, int D)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, n = min(n_max, *nuniq);
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        const float4* s = reinterpret_cast<const float4*>(src + (size_t)row * D);
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)uid[row] * D);
+        for (int c = lane; c < D / 4; c += 64) { float4 v = d[c]; const float4 x = s[c]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; d[c] = v; }
+    }
+}
+hipError_t rows_add_indexed(hipStream_t st, float* dst, const float* src, const int32_t* uid, const int32_t* nuniq, int n_max, int D)
+{
+    if (n_max <= 0) return hipSuccess;
+    if (D & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_add_indexed_kernel, dim3(std::min((n_max + 3) / 4, 4096)), dim3(256), 0, st, dst, src, uid, nuniq, n_max, D);
     return hipGetLastError();
 }
 
