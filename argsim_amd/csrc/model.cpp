@@ -70,7 +70,8 @@ struct avae_ctx {
     // bf16-operand GEMM mode (compute_dtype = 1): converted operand panels
     unsigned short *bfA = nullptr, *bfB = nullptr; size_t bfA_cap = 0, bfB_cap = 0;
     unsigned short* bfP = nullptr; size_t bfP_cap = 0;     // bf16 mode: (softmax - onehot)/N as written by softmax_ce_kernel, (N,V) bf16
-    struct Stamp { hipEvent_t a, b; int cls; double flops; };
+    // (dyn / dyn_max: a GEMM whose M or K is a device-side count -- its FLOPs are scaled by count / static bound at collection)
+    struct Stamp { hipEvent_t a, b; int cls; double flops; const int* dyn; int dyn_max; };
     std::vector<Stamp> stamps; size_t stamps_used = 0;
 };
 
@@ -96,7 +97,7 @@ int fail(avae_ctx* h, const std::string& m) { h->err = m; return 1; }
 // kernel classes for the timing hook: 0 = MFMA GEMM, 1 = GRU forward, 2 = GRU backward
 struct Timed {
     avae_ctx* h; avae_ctx::Stamp* s = nullptr;
-    Timed(avae_ctx* h_, int cls, double flops) : h(h_) {
+    Timed(avae_ctx* h_, int cls, double flops, const int* dyn = nullptr, int dyn_max = 0) : h(h_) {
         if (!h->timing) return;
         if (h->stamps_used == h->stamps.size()) {
             avae_ctx::Stamp n{};
@@ -104,7 +105,7 @@ struct Timed {
             h->stamps.push_back(n);
         }
         s = &h->stamps[h->stamps_used++];
-        s->cls = cls; s->flops = flops;
+        s->cls = cls; s->flops = flops; s->dyn = dyn; s->dyn_max = dyn_max;
         (void)hipEventRecord(s->a, h->stream);
     }
     ~Timed() { if (s) (void)hipEventRecord(s->b, h->stream); }
@@ -238,7 +239,7 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
     }
     GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin,
                pair ? pair->A : nullptr, pair ? pair->B : nullptr, pair ? pair->C : nullptr, pair ? pair->bias : nullptr};
-    Timed t(h, 0, 2.0 * M * N * K * (pair ? 2 : 1));
+    Timed t(h, 0, 2.0 * M * N * K * (pair ? 2 : 1), dyn, dyn_kind == 1 ? M : (dyn_kind == 2 ? K : 0));
     if (h->cfg.compute_dtype == 1) {
         // bf16 operands: convert (transposing [k][x] operands) into k-contiguous panels, then one NT kernel
         const int Kp = (K + 7) & ~7;
@@ -262,7 +263,7 @@ int gemm_bf16_pre(avae_ctx* h, const unsigned short* A16, int lda16, bool a_mc, 
                   int M, int N, int K, float alpha, int accumulate, int split_k, const int* dyn, int dyn_kind)
 {
     GemmArgs g{nullptr, Bm, C, nullptr, M, N, K, lda16, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, 0, nullptr, nullptr, nullptr, nullptr};
-    Timed t(h, 0, 2.0 * M * N * K);
+    Timed t(h, 0, 2.0 * M * N * K, dyn, dyn_kind == 1 ? M : (dyn_kind == 2 ? K : 0));
     const int Kp = (K + 7) & ~7;
     const unsigned short* Ap = A16; int lda_p = lda16;
     if (a_mc) {
@@ -926,7 +927,14 @@ int avae_debug_timing(avae_handle h, double* out, int max_n, int* n)
     for (int i = 0; i < *n; ++i) {
         float ms = 0.f;
         AV_CHECK(hipEventElapsedTime(&ms, h->stamps[i].a, h->stamps[i].b));
-        out[3 * i] = h->stamps[i].cls; out[3 * i + 1] = ms; out[3 * i + 2] = h->stamps[i].flops;
+        double fl = h->stamps[i].flops;
+        if (h->stamps[i].dyn && h->stamps[i].dyn_max > 0) {
+            // the count this launch ran with, as far as it is still on the device (the last step's; the bench repeats one batch)
+            int c = 0;
+            AV_CHECK(hipMemcpy(&c, h->stamps[i].dyn, sizeof(int), hipMemcpyDeviceToHost));
+            fl *= (double)std::max(0, std::min(c, h->stamps[i].dyn_max)) / (double)h->stamps[i].dyn_max;
+        }
+        out[3 * i] = h->stamps[i].cls; out[3 * i + 1] = ms; out[3 * i + 2] = fl;
     }
     return 0;
 }
