@@ -556,10 +556,8 @@ hipError_t latent_bwd(hipStream_t st, const float* dz, const float* mu, const fl
 }
 
 // ---------------------------------------------------------------- softmax cross-entropy (model.py:170-181)
-// one workgroup per compact row: pass 1 online max / sum-exp / first-argmax / label pick,
-// pass 2 (optional) overwrites the row with (softmax - onehot) * scale.
-// REG: V <= 8192 -- the row (<= 32 floats per thread) is read ONCE and stays in registers between the two passes
-// (1 read + 1 write of the logits instead of 2 + 1: this kernel is HBM-bound)
+// softmax cross-entropy, argmax and error flags of one compact row per workgroup (model.py:170-181); optionally the
+// gradient (softmax - onehot) * scale in place of the logits, or as the bf16 GEMM operand (grad16).
 // The V <= 8192 form (row in registers).  It was VALU-bound, not HBM-bound: the online max / sum-exp update evaluated two
 // libm expf per element and the gradient pass a third (~80 instructions per element, 214 us for 545 MB).  Now: pass A finds
 // the row maximum and first argmax (no exponential), pass B replaces every kept logit by exp2((x - m) log2 e) -- ONE v_exp_f32
@@ -648,7 +646,7 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(CeArgs a)
     if (tid == 0 && a.loss_acc) atomicAdd(a.loss_acc, s_acc);
 }
 
-template <bool REG>
+// the streaming form for V > 8192 (row re-read for the gradient pass; online max / sum-exp)
 __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
 {
     __shared__ float s_m[4], s_s[4], s_bv[4]; __shared__ int s_bi[4];
@@ -662,19 +660,8 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
         float* x = a.logits + (size_t)row * a.V;
         const int label = a.gold[a.cidx[row]];
         float m = -INFINITY, s = 0.f, bv = -INFINITY; int bi = 0x7fffffff;
-        float4 keep[REG ? 8 : 1];
-        if (REG) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = tid * 4 + 1024 * q;
-                keep[q] = c < a.V ? *reinterpret_cast<const float4*>(x + c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < (REG ? 8 : (1 << 20)); ++q) {
-            const int c = tid * 4 + 1024 * q;
-            if (c >= a.V) break;
-            float4 v = REG ? keep[REG ? q : 0] : *reinterpret_cast<const float4*>(x + c);
+        for (int c = tid * 4; c < a.V; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + c);
             float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -713,11 +700,8 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
         }
         if (a.write_grad) {
             __syncthreads();     // x[label] read before overwrite
-#pragma unroll
-            for (int q = 0; q < (REG ? 8 : (1 << 20)); ++q) {
-                const int c = tid * 4 + 1024 * q;
-                if (c >= a.V) break;
-                float4 v = REG ? keep[REG ? q : 0] : *reinterpret_cast<const float4*>(x + c);
+            for (int c = tid * 4; c < a.V; c += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(x + c);
                 float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] = (expf(e[k] - lse) - ((c + k) == label ? 1.f : 0.f)) * scale;
@@ -740,7 +724,7 @@ hipError_t softmax_ce(hipStream_t st, const CeArgs& a)
     if (a.n_max <= 0) return hipSuccess;
     if (a.V & 3) return hipErrorInvalidValue;
     if (a.V <= 8192) hipLaunchKernelGGL(softmax_ce_reg_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
-    else             hipLaunchKernelGGL(softmax_ce_kernel<false>, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    else             hipLaunchKernelGGL(softmax_ce_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
