@@ -336,6 +336,35 @@ def test_bf16_mode_team_kernels_track_the_register_form(B, S):
     m.close()
 
 
+@pytest.mark.parametrize("dtype", ['f32', 'bf16'])
+def test_table_fed_layers_equal_the_per_token_projection(dtype):
+    """Benchmark geometry (256 x 64 Zipf ids over 8192: more tokens than vocabulary entries): encoder layer 1 and decoder
+    layer 1 project only the ids present in the batch and gather / sum by id -- against the same library with
+    the per-token GEMMs (table_l1 = 0).  Forward: the same products in the same order per output element, so z and the
+    per-token losses agree to the last bits; backward: the same products grouped by id, another summation order."""
+    import torch
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=3, dtype=dtype, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    ids = synth.batch(256, 64, 8192, seed=4)
+    out = {}
+    for table in (1, 0):
+        m.set_option('table_l1', table)
+        z = m.encode(ids)
+        ev = m.eval(ids, ids)
+        m.forward_backward(ids, ids, seed=5)
+        out[table] = (z, ev, m.grads.clone(), m.losses(), m.get_grads()['embed/embedding'])
+    tz, tg = (1e-6, 2e-5) if dtype == 'f32' else (1e-2, 3e-2)      # (bf16: a last-bit difference can flip an operand rounding)
+    assert np.isfinite(out[1][0]).all() and np.abs(out[1][0] - out[0][0]).max() <= tz
+    assert np.abs(np.asarray(out[1][1][1]) - np.asarray(out[0][1][1])).max() <= (1e-5 if dtype == 'f32' else 5e-2)      # per-token CE
+    d = float((out[1][2] - out[0][2]).norm() / out[0][2].norm())
+    assert d < tg, d
+    # the embedding gradient on its own (the part that changes route: rows added by uid instead of scatter-added by token)
+    assert np.linalg.norm(out[1][4] - out[0][4]) < tg * np.linalg.norm(out[0][4])
+    m.close()
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f) row 2
 @pytest.mark.parametrize("b", [1, 5, 32])
 def test_persistent_greedy_decode_equals_the_per_token_loop(b):
