@@ -874,6 +874,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     for (int gate = 0; gate < 3; ++gate) bR[gate] = J.bR[ht * 48 + gn * 3 + gate];
     const int own_wk = (ht * 16) / WK, own_q = ((ht * 16) % WK) / 16;
     const float* __restrict__ p_gi = J.gi;                  // read only, under no other name: its loads need not wait for this item's stores
+    const int32_t* __restrict__ p_girows = J.gi_rows;
     float* __restrict__ p_svw = J.sv;                       // written only, under no other name: later loads need not wait for them
     float* __restrict__ p_hpw = J.hp;
     float* __restrict__ p_hsw = J.hs;
@@ -943,7 +944,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)grow;      // (byte offsets below 2^32: team_geometry checks)
         float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, h0_own = 0.f;
         if (gate_thread) {
-            const u32x3 g3 = __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)((rix * (unsigned)a.ldg + ht * 48 + gn * 3) * 4u), 0, 0);
+            const unsigned grix = p_girows ? (unsigned)p_girows[rix] : rix;          // (table-fed layer: the row of the per-id projection)
+            const u32x3 g3 = __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)((grix * (unsigned)a.ldg + ht * 48 + gn * 3) * 4u), 0, 0);
             gi0 = __uint_as_float(g3.x); gi1 = __uint_as_float(g3.y); gi2 = __uint_as_float(g3.z);
             if constexpr (BF) { if (p == 0 && J.h0 != nullptr) h0_own = bload1(rs_h0, ((unsigned)grow * D + j) * 4u); }
         }
@@ -1914,19 +1916,28 @@ static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int ld
     return hipGetLastError();
 }
 
+static bool forward_team(const GruArgs& a, bool persistent, int* T, int* C)
+{
+    if (!(persistent && a.p_end - a.p_begin > 1)) return false;
+    bool team = team_geometry(a, true, T, C) && a.item_pipeline == 2;
+#ifdef AVAE_DIAG
+    if (a.ablate && ((a.ablate & ~(16 | 128 | 256)) || *T != 4)) team = false;
+#else
+    if (a.ablate) team = false;
+#endif
+    return team;
+}
+bool gru_forward_uses_team(const GruArgs& a, bool persistent) { int T = 0, C = 0; return forward_team(a, persistent, &T, &C); }
+
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
+    int T = 0, C = 0;
+    const bool team = forward_team(a, persistent, &T, &C);
+    for (int i = 0; i < a.njobs; ++i) if (a.job[i].gi_rows && !team) return hipErrorInvalidValue;      // only the team kernels index gi through gi_rows
     if (persistent && a.p_end - a.p_begin > 1) {
         // D = 512: independent 16-row teams sharing one LDS-resident weight slice per CU, the row blocks of a workgroup
         // interleaved item by item (team_geometry picks 4 teams x 4 waves or 2 teams x 8 waves)
-        int T = 0, C = 0;
-        bool team = team_geometry(a, true, &T, &C) && a.item_pipeline == 2;
-#ifdef AVAE_DIAG
-        if (a.ablate && ((a.ablate & ~(16 | 128 | 256)) || T != 4)) team = false;
-#else
-        if (a.ablate) team = false;
-#endif
         e = prepare_exchange(st, a, true, team); if (e != hipSuccess) return e;
         if (team) {
             const int lds_bytes = (96 * 256 + 48 * 256 + 4 * 256) * 4 + 128;

@@ -52,6 +52,8 @@ hipError_t transpose_bf16(hipStream_t st, const unsigned short* src, int ld, int
 constexpr int kMaxGruJobs = 3;
 struct GruJob {
     const float* gi;      // + job column offset; row (pos*B + b) at gi + (pos*B+b)*ldg
+    const int32_t* gi_rows;   // optional (team kernels only): row gi_rows[pos*B + b] instead -- a layer fed by embedding rows reads
+                          // its projection straight out of the per-id table (model.cpp use_table), no per-token copy
     const float* R;       // (3D, D) G16 rows
     const float* bR;      // (3D) G16
     const float* h0;      // (B, D) or nullptr (zeros)
@@ -87,6 +89,7 @@ struct GruArgs {
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
+bool gru_forward_uses_team(const GruArgs& a, bool persistent);      // true: the launch runs the LDS-weight team kernels (gi_rows honoured)
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
 bool gru_dim_supported(int D);
 bool gru_diag_build();     // true: built with -DAVAE_DIAG (ablation / stamp instantiations present)
@@ -121,6 +124,8 @@ hipError_t id_groups_build(hipStream_t st, const int32_t* ids, int n, int V, int
 const int32_t* id_groups_rank(int32_t* scratch, int n, int V);     // [V]  index among the present ids, -1 absent
 const int32_t* id_groups_uid(int32_t* scratch, int n, int V);      // [V]  present ids, ascending
 const int32_t* id_groups_count(int32_t* scratch, int n, int V);    // [1]  how many
+// out[t] = rank[ids[t]]
+hipError_t rank_rows(hipStream_t st, int32_t* out, const int32_t* ids, const int32_t* rank, int n, int V);
 hipError_t rows_gather_ranked(hipStream_t st, float* dst, const float* src, const int32_t* ids, const int32_t* rank, int n, int W, int V);
 hipError_t rows_group_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch);
 hipError_t rows_add_indexed(hipStream_t st, float* dst, const float* src, const int32_t* uid, const int32_t* nuniq, int n_max, int D);

@@ -127,6 +127,7 @@ struct Ws {
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
     int32_t* scat;                        // embed_scatter_add2's token lists
     int32_t *grp_src, *grp_tgt;           // id_groups_build scratch of the two id sources (use_table)
+    int32_t *tokrow_src, *tokrow_tgt;
     float* xbuf; size_t xbuf_floats;      // exchange scratch of the GRU team kernels (GruArgs::xbuf)
 };
 
@@ -150,6 +151,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
     w.ew = b.take<float>((size_t)V * 6 * D);      // W E over the present ids (use_table): (U, 6D) encoder layer 1, then (U, 3D) decoder layer 1
     w.grp_src = b.take<int32_t>(id_groups_ints(rs, V)); w.grp_tgt = b.take<int32_t>(id_groups_ints(rt, V));     // token groups by id
+    w.tokrow_src = b.take<int32_t>(rs); w.tokrow_tgt = b.take<int32_t>(rt);      // row of the per-id projection for every token
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
     w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
@@ -405,16 +407,21 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             AV_CHECK(id_groups_build(h->stream, w.src_tm, rs, V, w.grp_src, save));
             AV_CHECK(rows_gather(h->stream, w.emb_src, h->P + h->oE, id_groups_uid(w.grp_src, rs, V), cnt, std::min(V, rs), D));
             AV_TRY(gemm(h, false, false, w.emb_src, D, h->P + p.W, D, w.ew, 6 * D, std::min(V, rs), 6 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
-            AV_CHECK(rows_gather_ranked(h->stream, w.e_gi[0], w.ew, w.src_tm, id_groups_rank(w.grp_src, rs, V), rs, 6 * D, V));
         } else
         AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, 6 * D, In, 1.f, h->P + p.bW));
         GruArgs a{};
         a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        // table-fed layer: the team kernels read gi straight out of the per-id projection through a row index per token;
+        // the other kernel forms get a per-token copy
+        const bool table0 = i == 0 && table, indirect = table0 && gru_forward_uses_team(a, h->persistent != 0);
+        if (indirect) AV_CHECK(rank_rows(h->stream, w.tokrow_src, w.src_tm, id_groups_rank(w.grp_src, rs, V), rs, V));
+        else if (table0) AV_CHECK(rows_gather_ranked(h->stream, w.e_gi[0], w.ew, w.src_tm, id_groups_rank(w.grp_src, rs, V), rs, 6 * D, V));
         for (int d = 0; d < 2; ++d) {
             GruJob& j = a.job[d];
-            j.gi = w.e_gi[i] + d * 3 * D;
+            j.gi = (indirect ? w.ew : w.e_gi[i]) + d * 3 * D;
+            j.gi_rows = indirect ? w.tokrow_src : nullptr;
             j.R = h->P + p.R + (int64_t)d * 3 * D * D;
             j.bR = h->P + p.bR + d * 3 * D;
             j.h0 = nullptr;
@@ -456,7 +463,6 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
             AV_CHECK(id_groups_build(h->stream, ids0, rt, V, w.grp_tgt, save));
             AV_CHECK(rows_gather(h->stream, w.emb_tgt, h->P + h->oE, id_groups_uid(w.grp_tgt, rt, V), cnt, std::min(V, rt), D));
             AV_TRY(gemm(h, false, false, w.emb_tgt, D, h->P + p.W, D, w.ew, 3 * D, std::min(V, rt), 3 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
-            AV_CHECK(rows_gather_ranked(h->stream, w.d_gi[0], w.ew, ids0, id_groups_rank(w.grp_tgt, rt, V), rt, 3 * D, V));
         } else
         AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
         GruArgs a{};
@@ -464,7 +470,11 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
-        j.gi = w.d_gi[i]; j.R = h->P + p.R; j.bR = h->P + p.bR;
+        const bool table0 = i == 0 && ids0, indirect = table0 && gru_forward_uses_team(a, h->persistent != 0);
+        if (indirect) AV_CHECK(rank_rows(h->stream, w.tokrow_tgt, ids0, id_groups_rank(w.grp_tgt, rt, h->cfg.dim_tgt), rt, h->cfg.dim_tgt));
+        else if (table0) AV_CHECK(rows_gather_ranked(h->stream, w.d_gi[0], w.ew, ids0, id_groups_rank(w.grp_tgt, rt, h->cfg.dim_tgt), rt, 3 * D, h->cfg.dim_tgt));
+        j.gi = indirect ? w.ew : w.d_gi[i]; j.gi_rows = indirect ? w.tokrow_tgt : nullptr;
+        j.R = h->P + p.R; j.bR = h->P + p.bR;
         j.h0 = state_in + state_stride * i;
         j.hs = w.d_hd[i];
         j.sv = save ? w.d_sv[i] : nullptr;

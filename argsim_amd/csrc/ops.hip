@@ -351,6 +351,20 @@ __global__ __launch_bounds__(256) void rows_gather_ranked_kernel(float* __restri
         for (int c = lane; c < W / 4; c += 64) d[c] = s[c];
     }
 }
+__global__ __launch_bounds__(256) void rank_rows_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ ids, const int32_t* __restrict__ rank, int n, int V)
+{
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        int id = ids[t];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        out[t] = rank[id];
+    }
+}
+hipError_t rank_rows(hipStream_t st, int32_t* out, const int32_t* ids, const int32_t* rank, int n, int V)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_rows_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, out, ids, rank, n, V);
+    return hipGetLastError();
+}
 hipError_t rows_gather_ranked(hipStream_t st, float* dst, const float* src, const int32_t* ids, const int32_t* rank, int n, int W, int V)
 {
     if (n <= 0) return hipSuccess;
