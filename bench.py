@@ -30,6 +30,7 @@ CFG = dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 B, S = 256, 64
 PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA = 2500.0    # TFLOP/s dense (same table)
+STAMP_EVERY = 8            # every n-th timed step carries the per-launch HIP-event stamps of the roofline leg
 PMC_TAG = 'r02'            # the committed rocprofv3 --pmc passes `traffic` / `mfma_busy` are read from
 
 
@@ -194,18 +195,18 @@ def main():
     fence()
     timing = world == 1 and not A.no_timing
     # HIP-event stamps around every GEMM / GRU launch cost ~8 us of stream gap each (0.5 ms per step when
-    # every step is stamped), so only every 4th step of the timed region is stamped: the roofline figures
-    # are live measurements over the timed region, `value` is perturbed by < 0.6 %
-    stamped = [i for i in range(A.steps) if i % 4 == 0] if timing else []
+    # every step is stamped), so only every 8th step of the timed region is stamped (3 of the default 20): the
+    # roofline figures are live measurements over the timed region, `value` is perturbed by < 0.4 %
+    stamped = [i for i in range(A.steps) if i % STAMP_EVERY == 0] if timing else []
     if timing:
         model.set_option('timing', 1)          # resets the stamp list
         model.set_option('timing_pause', 1)
     t0 = time.perf_counter()
     for i in range(A.steps):
-        if timing and i % 4 == 0:
+        if timing and i % STAMP_EVERY == 0:
             model.set_option('timing_pause', 0)
         one(A.warmup + i)
-        if timing and i % 4 == 0:
+        if timing and i % STAMP_EVERY == 0:
             model.set_option('timing_pause', 1)
     fence()
     dt = time.perf_counter() - t0
