@@ -22,9 +22,15 @@ def batch(seed):
     return x
 
 
+# MODES=round2: the default path (layers fed by embedding rows project the present ids) against the per-token
+# projection (table_l1 = 0) and the bf16-operand mode, same seeds
+ROUND2 = os.environ.get('MODES') == 'round2'
+RUNS = (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0}), ('f32s', 'bf16', {})) if ROUND2 else (('f32', 'f32', {}), ('f32 again', 'f32', {}), ('f32s', 'f32s', {}))
 curves = {}
-for tag, dt in (('f32', 'f32'), ('f32 again', 'f32'), ('f32s', 'f32s')):
+for tag, dt, opts in RUNS:
     m = VAE('train', seed=0, dtype=dt, dim_tgt=V, dim_emb=512, dim_rep=128, rnn_layers=3)
+    for k, v in opts.items():
+        m.set_option(k, v)
     out = []
     for i in range(STEPS):
         x = batch(i)
@@ -35,7 +41,8 @@ for tag, dt in (('f32', 'f32'), ('f32 again', 'f32'), ('f32s', 'f32s')):
     del m
     torch.cuda.empty_cache()
 # 'f32 again' = the same exact-fp32 mode a second time: gradients use float atomics, so two runs of ONE mode drift apart too
-print('step   loss_gen f32   f32 again (rel diff)     f32s (rel diff)   |  loss_kld f32   f32 again        f32s')
+print('step   loss_gen f32   f32 again (rel diff)     f32s (rel diff)   |  loss_kld f32   f32 again        f32s' if not ROUND2 else
+      'step   loss_gen f32   per-token projection (rel diff)   bf16 mode (rel diff)   |  loss_kld f32   per-token      bf16')
 for a, c, b in zip(curves['f32'], curves['f32 again'], curves['f32s']):
     print('%4d   %12.6f   %10.6f (%7.1e)   %10.6f (%7.1e) |  %12.6f  %10.6f  %10.6f' %
           (a[0], a[1], c[1], abs(a[1] - c[1]) / abs(a[1]), b[1], abs(a[1] - b[1]) / abs(a[1]), a[2], c[2], b[2]))
