@@ -398,13 +398,22 @@ __global__ __launch_bounds__(256) void scatter_reduce_wide_kernel(Scatter2 a, fl
         else { atomicAdd(d, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w); }
     }
 }
-// dst (rows of the present ids, W floats each; zero-filled here up to min(V, n) rows) = per-id sums of src's rows
+// only the rows that several segments ADD into need zeros first (the hot ids: a few rows); every other present row is stored
+__global__ __launch_bounds__(256) void zero_hot_rows_kernel(Scatter2 a, float* __restrict__ dst, int W)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int id = blockIdx.x * wpb + (threadIdx.x >> 6); id < a.V; id += gridDim.x * wpb) {
+        if (a.off[id + 1] - a.off[id] <= kScatterSeg) continue;
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)a.rank[id] * W);
+        for (int c = lane; c < W / 4; c += 64) d[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// dst (rows of the present ids, W floats each; rows beyond their count are left untouched) = per-id sums of src's rows
 hipError_t rows_group_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch)
 {
     if ((W & 3) || n <= 0 || V > kScatterLdsV) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(dst, 0, sizeof(float) * (size_t)std::min(V, n) * W, st);
-    if (e != hipSuccess) return e;
     Scatter2 a = id_groups_view(ids, n, V, scratch);
+    hipLaunchKernelGGL(zero_hot_rows_kernel, dim3(std::min((V + 3) / 4, 2048)), dim3(256), 0, st, a, dst, W);
     const long long items = ((long long)n / 8 + V) * ((W + 255) / 256);
     hipLaunchKernelGGL(scatter_reduce_wide_kernel, dim3((unsigned)std::min<long long>((items + 3) / 4, 8192)), dim3(256), 0, st, a, dst, src, W);
     return hipGetLastError();
