@@ -191,21 +191,34 @@ __global__ __launch_bounds__(256) void scatter_hist_kernel(Scatter2 a)
     __syncthreads();
     for (int i = tid; i < a.V; i += 256) { const int c = lc[i]; if (c) atomicAdd(a.cnt + i, c); }
 }
+// inclusive scan of one int per thread over a 1024-thread workgroup: wave scans by lane shuffles, the 16 wave totals by
+// the first wave (two barriers instead of the twenty of a shared-memory doubling scan)
+__device__ __forceinline__ int block_scan1024(int v, int* wsum /* [16] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(w, o, 64); if (lane >= o) w += t; }
+        if (lane < 16) wsum[lane] = w;
+    }
+    __syncthreads();
+    const int r = v + (wave ? wsum[wave - 1] : 0);
+    __syncthreads();                                 // (wsum is reused by the next scan)
+    return r;
+}
 __global__ __launch_bounds__(1024) void scatter_scan_kernel(Scatter2 a)        // one workgroup: V is a few thousand
 {
-    __shared__ int s_tok[1024], s_seg[1024], s_uni[1024];
+    __shared__ int wsum[16];
     const int tid = threadIdx.x, per = (a.V + 1023) / 1024, beg = min(a.V, tid * per), end = min(a.V, beg + per);
     int tok = 0, seg = 0, uni = 0;
     for (int i = beg; i < end; ++i) { const int c = a.cnt[i]; tok += c; seg += (c + kScatterSeg - 1) / kScatterSeg; uni += c > 0; }
-    s_tok[tid] = tok; s_seg[tid] = seg; s_uni[tid] = uni;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int vt = tid >= o ? s_tok[tid - o] : 0, vs = tid >= o ? s_seg[tid - o] : 0, vu = tid >= o ? s_uni[tid - o] : 0;
-        __syncthreads();
-        s_tok[tid] += vt; s_seg[tid] += vs; s_uni[tid] += vu;
-        __syncthreads();
-    }
-    int rt = s_tok[tid] - tok, rs = s_seg[tid] - seg, ru = s_uni[tid] - uni;
+    const int itok = block_scan1024(tok, wsum), iseg = block_scan1024(seg, wsum), iuni = block_scan1024(uni, wsum);
+    int rt = itok - tok, rs = iseg - seg, ru = iuni - uni;
     for (int i = beg; i < end; ++i) {
         const int c = a.cnt[i];
         a.off[i] = rt; a.segoff[i] = rs;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(Scatter2 a)        /
         for (int k = (c + kScatterSeg - 1) / kScatterSeg; k > 0; --k) a.segid[rs++] = i;
         if (a.rank) { a.rank[i] = c > 0 ? ru : -1; if (c > 0) a.uid[ru++] = i; }
     }
-    if (tid == 1023) { a.off[a.V] = s_tok[1023]; a.segoff[a.V] = s_seg[1023]; if (a.rank) a.nuniq[0] = s_uni[1023]; }
+    if (tid == 1023) { a.off[a.V] = itok; a.segoff[a.V] = iseg; if (a.rank) a.nuniq[0] = iuni; }
 }
 __global__ __launch_bounds__(256) void scatter_fill_kernel(Scatter2 a)
 {
