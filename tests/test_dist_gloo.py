@@ -119,3 +119,75 @@ def test_shard_rows_and_reducer_bookkeeping():
     assert [shard_rows(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
     with pytest.raises(AssertionError):
         shard_rows(10, 0, 4)
+
+
+def test_rccl_path_puts_every_collective_into_the_side_streams_order(monkeypatch):
+    """The RCCL branch of GradReducer (no GPU or RCCL here: streams, events and the collective are stand-ins that log what
+    is asked of them).  A collective runs on the process group's own stream; Work.wait() only makes the CURRENT stream wait
+    for it.  It must therefore be taken at once, inside the side-stream context -- then the fence before a persistent GRU
+    launch (compute stream waits for the side stream) really is ordered after every collective in flight."""
+    import torch.distributed as tdist
+    from argsim_amd import dist as D
+    log = []
+
+    class Stream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append((self.name, 'wait_event'))
+
+        def wait_stream(self, other):
+            log.append((self.name, 'wait_stream', other.name))
+
+    comm, main = Stream('comm'), Stream('main')
+    current = [main]
+
+    class Ctx:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            self.prev, current[0] = current[0], self.s
+
+        def __exit__(self, *a):
+            current[0] = self.prev
+
+    class Event:
+        def record(self, s):
+            log.append((s.name, 'record'))
+
+    class Work:
+        def wait(self):
+            log.append((current[0].name, 'work.wait'))
+
+    def all_reduce(*a, **k):
+        assert k.get('async_op') is True
+        log.append((current[0].name, 'all_reduce'))
+        return Work()
+
+    monkeypatch.setattr(torch.cuda, 'Event', Event)
+    monkeypatch.setattr(torch.cuda, 'stream', Ctx)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: current[0])
+    monkeypatch.setattr(tdist, 'get_backend', lambda g=None: 'nccl')
+    monkeypatch.setattr(tdist, 'all_reduce', all_reduce)
+    r = D.GradReducer(torch.zeros(8), [(0, 4), (4, 4)], None, comm)
+    assert r.stream_ordered
+    r.reduce_bucket(0)
+    assert log == [('main', 'record'), ('comm', 'wait_event'), ('comm', 'all_reduce'), ('comm', 'work.wait')]
+    assert not r.pending and current[0] is main
+    log.clear()
+    r.fence()
+    assert log == [('main', 'wait_stream', 'comm')]
+    log.clear()
+    r.reduce_bucket(1)
+    r.wait()
+    assert log[-1] == ('main', 'wait_stream', 'comm') and ('comm', 'work.wait') in log
+    # gloo (host-completed collectives) keeps its Work objects and waits for them in fence() / wait()
+    monkeypatch.setattr(tdist, 'get_backend', lambda g=None: 'gloo')
+    g = D.GradReducer(torch.zeros(8), [(0, 8)], None, comm)
+    log.clear()
+    g.reduce_bucket(0)
+    assert not g.stream_ordered and len(g.pending) == 1 and ('comm', 'work.wait') not in log
+    g.fence()
+    assert not g.pending and ('main', 'work.wait') in log and log[-1] == ('main', 'wait_stream', 'comm')
