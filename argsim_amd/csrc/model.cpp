@@ -47,6 +47,7 @@ struct avae_ctx {
     avae_grad_hook hook = nullptr; void* hook_user = nullptr;
     std::vector<int> hook_pending;     // buckets complete but not yet announced (see hook_flush)
     int persistent = 1;
+    bool first_step_checked = false;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
@@ -73,6 +74,7 @@ struct avae_ctx {
     // (dyn / dyn_max: a GEMM whose M or K is a device-side count -- its FLOPs are scaled by count / static bound at collection)
     struct Stamp { hipEvent_t a, b; int cls; double flops; const int* dyn; int dyn_max; };
     std::vector<Stamp> stamps; size_t stamps_used = 0;
+    const int32_t *cnt_src = nullptr, *cnt_tgt = nullptr;     // present-id counts of the last forward (table-fed layers), device
 };
 
 namespace {
@@ -141,6 +143,14 @@ struct Bump {
     }
 };
 
+// A layer whose input is an embedding row (encoder layer 1: E[src]; decoder layer 1: E[lead]) computes W E[id].  With more
+// tokens than vocabulary entries the projection is taken once over the U <= V ids present in the batch (their E rows
+// gathered, one GEMM with a device-side row count) and gathered by id; the backward sums the per-token gate gradients by id
+// (rows_group_sum) and runs dW = (sum)^T E_present and dE[present] += (sum) W over U rows.  The same products grouped by id:
+// exact algebra, a different summation order in the backward.  The compact E rows live in emb_src / emb_tgt (unused
+// otherwise in this mode), the per-id gradient of E in demb_src / demb_tgt.
+static bool use_table(const avae_ctx* h, int rows) { return h->table_l1 && rows >= h->cfg.dim_tgt && id_groups_supported(h->cfg.dim_tgt); }
+
 void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
 {
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
@@ -149,9 +159,12 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.lead = b.take<int32_t>(rt); w.gold = b.take<int32_t>(rt); w.rank = b.take<int32_t>(rt);
     w.cidx = b.take<int32_t>(rt); w.ntok = b.take<int32_t>(4 + kPrepChunks); w.pred = b.take<int32_t>(rt);      // (ntok[4..]: prep_ids' chunk counts)
     w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
-    w.ew = b.take<float>((size_t)V * 6 * D);      // W E over the present ids (use_table): (U, 6D) encoder layer 1, then (U, 3D) decoder layer 1
-    w.grp_src = b.take<int32_t>(id_groups_ints(rs, V)); w.grp_tgt = b.take<int32_t>(id_groups_ints(rt, V));     // token groups by id
-    w.tokrow_src = b.take<int32_t>(rs); w.tokrow_tgt = b.take<int32_t>(rt);      // row of the per-id projection for every token
+    // table-fed first layers (use_table), taken only where this geometry runs them: W E over the present ids ((U, 6D) encoder
+    // layer 1, then (U, 3D) decoder layer 1), the token groups of the id source, the projection row of every token
+    const bool tab_s = use_table(h, (int)rs), tab_t = use_table(h, (int)rt);
+    w.ew = b.take<float>(tab_s ? (size_t)V * 6 * D : (tab_t ? (size_t)V * 3 * D : 0));
+    w.grp_src = b.take<int32_t>(tab_s ? id_groups_ints(rs, V) : 0); w.grp_tgt = b.take<int32_t>(tab_t ? id_groups_ints(rt, V) : 0);
+    w.tokrow_src = b.take<int32_t>(tab_s ? rs : 0); w.tokrow_tgt = b.take<int32_t>(tab_t ? rt : 0);
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
     w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
@@ -193,7 +206,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.dgi_e = b.take<float>(rs * 6 * D); w.dgh_e = b.take<float>(rs * 6 * D);
         w.demb_src = b.take<float>(rs * D); w.demb_tgt = b.take<float>(rt * D);
         w.scat = b.take<int32_t>(embed_scatter_scratch_ints(rs + rt, V));
-        w.dew = b.take<float>((size_t)V * 6 * D);  // gate gradients of a table-fed layer summed by id
+        w.dew = b.take<float>(tab_s ? (size_t)V * 6 * D : (tab_t ? (size_t)V * 3 * D : 0));  // gate gradients of a table-fed layer summed by id
     }
 }
 
@@ -206,6 +219,8 @@ int get_ws(avae_ctx* h, Ws& w, int B, int Ss, int St, bool train)
         AV_CHECK(hipStreamSynchronize(h->stream));
         if (h->ws) AV_CHECK(hipFree(h->ws));
         h->ws = nullptr; h->ws_cap = 0;
+        h->cnt_src = h->cnt_tgt = nullptr;                    // (pointed into the old arena)
+        for (auto& sp : h->stamps) sp.dyn = nullptr;
         size_t cap = need + need / 8;
         AV_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), cap));
         h->ws_cap = cap;
@@ -384,20 +399,13 @@ Sched schedule(const avae_ctx* h)
     return s;
 }
 
-// A layer whose input is an embedding row (encoder layer 1: E[src]; decoder layer 1: E[lead]) computes W E[id].  With more
-// tokens than vocabulary entries the projection is taken once over the U <= V ids present in the batch (their E rows
-// gathered, one GEMM with a device-side row count) and gathered by id; the backward sums the per-token gate gradients by id
-// (rows_group_sum) and runs dW = (sum)^T E_present and dE[present] += (sum) W over U rows.  The same products grouped by id:
-// exact algebra, a different summation order in the backward.  The compact E rows live in emb_src / emb_tgt (unused
-// otherwise in this mode), the per-id gradient of E in demb_src / demb_tgt.
-static bool use_table(const avae_ctx* h, int rows) { return h->table_l1 && rows >= h->cfg.dim_tgt && id_groups_supported(h->cfg.dim_tgt); }
-
 // -------------------------------------------------------------------------------- forward pieces
 int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 {
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
     const int rs = Ss * B;
     const bool table = use_table(h, rs);
+    h->cnt_src = table ? id_groups_count(w.grp_src, rs, V) : nullptr;
     if (!table) AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.src_tm, w.emb_src, rs, D, V));
     const float* x = w.emb_src; int In = D;
     for (int i = 0; i < L; ++i) {
@@ -455,6 +463,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
     const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
     const int rt = T * B;
     const float* x = w.emb_tgt;
+    h->cnt_tgt = ids0 ? id_groups_count(w.grp_tgt, rt, h->cfg.dim_tgt) : nullptr;
     for (int i = 0; i < L; ++i) {
         const GruP& p = h->dec[i];
         if (i == 0 && ids0) {       // (ids0: the layer input is E[ids0], not yet gathered -- use_table decided by the caller)
@@ -565,8 +574,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         AV_TRY(gemm_bf16_pre(h, h->bfP, V, true, w.ho, D, true, G + h->oE, D, V, D, rt, isd, s > 1 ? 0 : 1, s, w.ntok, 2));
     } else {
     AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1, true));
-    // (V x D output over K = N rows: 1024 tiles of 64x64, one K slice, plain stores -- no atomics, deterministic; G was
-    //  zero-filled above and the gather part is scatter-added at the end)
+    // (V x D output over K = N rows: 256 tiles of 128x128 x 3 K slices, float atomics into the zero-filled G; the gather
+    //  part is scatter-added at the end)
     AV_TRY(gemm_tn_grad(h, w.logits, V, w.ho, D, G + h->oE, D, V, D, rt, isd, w.ntok));
     }
     // out affine
@@ -635,7 +644,6 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
 
     // encoder stack
     cur = 0;
-    bool emb_done = false;
     for (int i = L - 1; i >= 0; --i) {
         const GruP& p = h->enc[i];
         const int In = i == 0 ? D : 2 * D;
@@ -656,34 +664,40 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         hook_flush(h);
         const bool table = i == 0 && use_table(h, rs);
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
-        if (table) {
-            // table-fed layer (use_table).  Its contribution completes the embedding gradient, so that bucket is announced
-            // FIRST and its all-reduce runs beside the two weight-gradient GEMMs below; this layer's own bucket ends backward.
-            const int32_t* cnt = id_groups_count(w.grp_src, rs, V); const int U = std::min(V, rs);
-            AV_CHECK(rows_group_sum(st, w.dew, w.src_tm, w.dgi_e, rs, 6 * D, V, w.grp_src));
-            AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, w.demb_src, D, U, D, 6 * D, 1.f, nullptr, 0, 0, cnt, 1));
-            AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_src, id_groups_uid(w.grp_src, rs, V), cnt, U, D));
-            AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, 0, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
+        float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
+        if (i == 0) {
+            // First encoder layer: its input gradient completes the embedding gradient.  That bucket is ALWAYS announced here,
+            // before this layer's two weight-gradient GEMMs (its all-reduce runs beside them), and this layer's own bucket
+            // ends backward -- in the table-fed form and in the per-token form alike.  The order of announcements must not
+            // depend on the batch shape: data-parallel ranks pad their shards to their own longest row, so one rank can be
+            // on either side of use_table() while its peer is on the other, and the collectives are paired by call order.
+            if (table) {
+                // table-fed layer (use_table): gate gradients summed by id, dE[present] += (sum) W over U rows
+                const int32_t* cnt = id_groups_count(w.grp_src, rs, V); const int U = std::min(V, rs);
+                AV_CHECK(rows_group_sum(st, w.dew, w.src_tm, w.dgi_e, rs, 6 * D, V, w.grp_src));
+                AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, w.demb_src, D, U, D, 6 * D, 1.f, nullptr, 0, 0, cnt, 1));
+                AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_src, id_groups_uid(w.grp_src, rs, V), cnt, U, D));
+            } else
+            AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
+            // gather gradients of the per-token forms on top of the logits term (a table-fed side has added its rows already)
+            AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, table ? 0 : rs, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
             fire_hook(h, 2 + 2 * L);
             hook_flush(h);
-            emb_done = true;
-            AV_TRY(gemm_tn_grad(h, w.dew, 6 * D, w.emb_src, D, G + p.W, D, 6 * D, D, U, 1.f, cnt));
+            if (table) {
+                const int32_t* cnt = id_groups_count(w.grp_src, rs, V); const int U = std::min(V, rs);
+                AV_TRY(gemm_tn_grad(h, w.dew, 6 * D, w.emb_src, D, G + p.W, D, 6 * D, D, U, 1.f, cnt));
+            } else
+            AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         } else
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         {   // dR of the two directions: same shape, one launch
             const Pair bwd{w.dgh_e + 3 * D, w.e_hp[1][i], G + p.R + (int64_t)3 * D * D, nullptr};
             AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, nullptr, &bwd));
         }
-        float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
-        if (!table)
+        if (i > 0)
         AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
         cur ^= 1;
         fire_hook(h, 2 + L + (L - 1 - i));
-        if (i == 0) hook_flush(h);         // no persistent launch follows: announce now, beside the embedding scatter-adds
-    }
-    if (!emb_done) {    // embedding: gather gradients on top of the logits term
-        AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
-        fire_hook(h, 2 + 2 * L);
     }
     hook_flush(h);
     return 0;
@@ -772,7 +786,10 @@ int check_gru_err(avae_ctx* h)
     AV_CHECK(hipStreamSynchronize(h->stream));
     if (e) {
         (void)hipMemsetAsync(h->errw, 0, sizeof(int), h->stream);
-        return fail(h, "GRU persistent kernel: group wait timed out (workgroups not co-resident?)");
+        return fail(h, "GRU persistent kernel: an exchange wait timed out -- its workgroups were not all resident at once.  A persistent "
+                       "launch needs every CU of the device (one handle = one GPU = one process, include/argsim_vae.h): another process or "
+                       "stream computing on this GPU holds CUs the launch is waiting for.  Give the handle the device to itself, or "
+                       "run with avae_set_option(\"persistent\", 0) (one launch per time step)");
     }
     return 0;
 }
@@ -911,20 +928,53 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "timing_pause")) { h->timing = value ? 0 : h->timing_on; return 0; }
     return fail(h, "unknown option");
 }
+// the row / depth count a dyn-count GEMM ran with, as a fraction of the static bound its stamp was priced at.  Only the
+// last step's count is still on the device (the bench repeats one batch, so it is every stamped step's count); each
+// distinct count word is read once per collection.
+static int dyn_fraction(avae_ctx* h, const avae_ctx::Stamp& s, std::vector<std::pair<const int*, int>>& seen, double* f)
+{
+    *f = 1.0;
+    if (!s.dyn || s.dyn_max <= 0) return 0;
+    int c = -1;
+    for (auto& e : seen) if (e.first == s.dyn) c = e.second;
+    if (c < 0) {
+        AV_CHECK(hipMemcpy(&c, s.dyn, sizeof(int), hipMemcpyDeviceToHost));
+        if (c < 0) c = 0;
+        seen.push_back({s.dyn, c});
+    }
+    *f = (double)std::min(c, s.dyn_max) / (double)s.dyn_max;
+    return 0;
+}
 // synchronises, sums the HIP-event durations recorded since timing was switched on / last collected:
-// out[3*c + 0..2] = total ms, launches, algorithmic FLOPs of kernel class c (0 GEMM, 1 GRU fwd, 2 GRU bwd)
+// out[3*c + 0..2] = total ms, launches, EXECUTED FLOPs of kernel class c (0 GEMM, 1 GRU fwd, 2 GRU bwd): a GEMM whose
+// row count or depth is a device-side count (the table-fed layers' present ids, the kept tokens) exits at that count,
+// so its 2MNK is scaled by count / static bound
 int avae_timing_collect(avae_handle h, double* out)
 {
     if (!h || !out) return 1;
     AV_CHECK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < 9; ++i) out[i] = 0.0;
+    std::vector<std::pair<const int*, int>> seen;
     for (size_t i = 0; i < h->stamps_used; ++i) {
         float ms = 0.f;
         AV_CHECK(hipEventElapsedTime(&ms, h->stamps[i].a, h->stamps[i].b));
+        double f = 1.0;
+        AV_TRY(dyn_fraction(h, h->stamps[i], seen, &f));
         int c = h->stamps[i].cls;
-        out[3 * c] += ms; out[3 * c + 1] += 1.0; out[3 * c + 2] += h->stamps[i].flops;
+        out[3 * c] += ms; out[3 * c + 1] += 1.0; out[3 * c + 2] += h->stamps[i].flops * f;
     }
     h->stamps_used = 0;
+    return 0;
+}
+// ids present in the last forward's two id sources (encoder input, decoder input) where those layers were table-fed
+// (use_table), else -1: out[0] = src, out[1] = tgt.  Synchronises.
+int avae_debug_present_ids(avae_handle h, int32_t out[2])
+{
+    if (!h || !out) return 1;
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    out[0] = out[1] = -1;
+    if (h->cnt_src) AV_CHECK(hipMemcpy(&out[0], h->cnt_src, sizeof(int), hipMemcpyDeviceToHost));
+    if (h->cnt_tgt) AV_CHECK(hipMemcpy(&out[1], h->cnt_tgt, sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 // diagnostic: per-launch (class, ms, FLOPs) triples of the stamps recorded since timing was switched on, in launch
@@ -934,16 +984,13 @@ int avae_debug_timing(avae_handle h, double* out, int max_n, int* n)
     if (!h || !out || !n) return 1;
     AV_CHECK(hipStreamSynchronize(h->stream));
     *n = (int)std::min<size_t>(h->stamps_used, (size_t)max_n);
+    std::vector<std::pair<const int*, int>> seen;
     for (int i = 0; i < *n; ++i) {
         float ms = 0.f;
         AV_CHECK(hipEventElapsedTime(&ms, h->stamps[i].a, h->stamps[i].b));
-        double fl = h->stamps[i].flops;
-        if (h->stamps[i].dyn && h->stamps[i].dyn_max > 0) {
-            // the count this launch ran with, as far as it is still on the device (the last step's; the bench repeats one batch)
-            int c = 0;
-            AV_CHECK(hipMemcpy(&c, h->stamps[i].dyn, sizeof(int), hipMemcpyDeviceToHost));
-            fl *= (double)std::max(0, std::min(c, h->stamps[i].dyn_max)) / (double)h->stamps[i].dyn_max;
-        }
+        double f = 1.0;
+        AV_TRY(dyn_fraction(h, h->stamps[i], seen, &f));
+        const double fl = h->stamps[i].flops * f;
         out[3 * i] = h->stamps[i].cls; out[3 * i + 1] = ms; out[3 * i + 2] = fl;
     }
     return 0;
@@ -984,6 +1031,12 @@ int avae_forward_backward(avae_handle h, const int32_t* src, const int32_t* tgt,
     h->B = B; h->Ss = Ss; h->St = St;
     AV_TRY(forward(h, w, src, tgt, B, Ss, St, true, seed, keep_mask, eps, n_tok_global > 0.f ? 1.f / n_tok_global : 0.f));
     AV_TRY(backward(h, w, B, Ss, St, b_global));
+    if (h->persistent && !h->first_step_checked) {
+        // the first step of a handle is checked at once (one synchronisation, once): a device shared with another process
+        // fails HERE with the message above instead of training on past time-outs until the losses are next fetched
+        h->first_step_checked = true;
+        AV_TRY(check_gru_err(h));
+    }
     return 0;
 }
 

@@ -183,6 +183,13 @@ class VAE:
         self._ck(self._l.avae_timing_collect(self._h, out))
         return {k: (out[3 * i], int(out[3 * i + 1]), out[3 * i + 2]) for i, k in enumerate(('gemm', 'gru_fwd', 'gru_bwd'))}
 
+    def present_ids(self):
+        """(src, tgt): distinct ids in the last forward's encoder / decoder input where that layer was table-fed, else -1"""
+        out = (C.c_int32 * 2)()
+        self._stream()
+        self._ck(self._l.avae_debug_present_ids(self._h, out))
+        return int(out[0]), int(out[1])
+
     def buckets(self):
         out = []
         for i in range(self._l.avae_bucket_count(self._h)):

@@ -77,9 +77,9 @@ def pinned(gen):
     """host batches -> page-locked torch tensors, so the H2D copy of VAE._ids is asynchronous (the counterpart of the
     tf.data iterator handing device-ready tensors to the graph, util_tf.py:16-23)"""
     import torch
-    for src, tgt in gen:
+    for src, tgt, *rest in gen:        # (rest: the global token count of a data-parallel batch, passed through)
         a = torch.from_numpy(src).pin_memory()
-        yield a, (a if tgt is src else torch.from_numpy(tgt).pin_memory())
+        yield (a, (a if tgt is src else torch.from_numpy(tgt).pin_memory()), *rest)
 
 
 def pipe(gen, prefetch=1):
@@ -103,13 +103,39 @@ def pipe(gen, prefetch=1):
         yield item
 
 
-def summ(model, valid, batch_valid):
-    """means over ALL validation tokens / latent elements (src/train.py:104-113)"""
+def summ(model, valid, batch_valid, rank=0, world=1, group=None):
+    """means over ALL validation tokens / latent elements (src/train.py:104-113).
+    Data parallel: the chunks of ``partition`` are dealt round-robin over the ranks and the six sums (errors, CE, tokens,
+    KL, latent elements) are added across them on the host-side group, so every rank validates 1/world of the array and
+    nobody waits in the next step's all-reduce while rank 0 walks the whole of it."""
     import numpy as np
     from .util_np import partition
-    parts = [model.eval(valid[i:j], valid[i:j]) for i, j in partition(len(valid), batch_valid, discard=False)]
-    errt, lgen, lkld = (np.concatenate([p[k].ravel() for p in parts]) for k in range(3))
-    return float(errt.mean()), float(lgen.mean()), float(lkld.mean())
+    chunks = list(partition(len(valid), batch_valid, discard=False))[rank::world]
+    parts = [model.eval(valid[i:j], valid[i:j]) for i, j in chunks]
+    if world == 1:
+        errt, lgen, lkld = (np.concatenate([p[k].ravel() for p in parts]) for k in range(3))
+        return float(errt.mean()), float(lgen.mean()), float(lkld.mean())
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([sum(float(p[0].sum(dtype=np.float64)) for p in parts), sum(float(p[1].sum(dtype=np.float64)) for p in parts),
+                      float(sum(p[0].size for p in parts)), sum(float(p[2].sum(dtype=np.float64)) for p in parts),
+                      float(sum(p[2].size for p in parts))], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    e, g, n, k, m = (float(x) for x in t)
+    return e / n, g / n, k / m
+
+
+def with_global_counts(gen, eos, group):
+    """(src, tgt) -> (src, tgt, N_global): the tokens of the GLOBAL batch, sum over ranks of sum_b (len_b + 1)
+    (model.py:181 is a mean over all of them).  One scalar all-reduce per batch on a HOST-side (gloo) group, issued from the
+    prefetch thread that runs this generator: the training loop never blocks on it and never reads a device scalar back
+    (a device all-reduce + .item() per step stalled the host behind the previous step's GPU work)."""
+    import torch
+    import torch.distributed as dist
+    for src, tgt in gen:
+        t = torch.tensor([float(int((tgt != eos).sum()) + len(tgt))], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        yield src, tgt, float(t[0])
 
 
 def profile(A, argv):
@@ -188,37 +214,41 @@ def main(argv=None):
     if not A.rounds:
         sys.exit("profiling done")
 
-    dp = None
+    dp = host_group = None
     if world > 1:
         import torch.distributed as dist
-        from .dist import DataParallel, global_token_count
+        from .dist import DataParallel
         dist.init_process_group('nccl')
+        host_group = dist.new_group(backend='gloo')      # host-side scalars (token counts, validation sums): never on the GPU's queue
         dp = DataParallel(model)
     if A.ckpt:
         ckpt.restore(model, pform(P.ckpt, A.ckpt))
     if dp:
         dp.broadcast_params(model.state)
 
-    stream = pipe(pinned(batch(T.batch_train, P.train, vocab, A.seed, A.sample, T.max_len, rank, world)), A.prefetch)
+    eos = vocab.eos_id()
+    batches = batch(T.batch_train, P.train, vocab, A.seed, A.sample, T.max_len, rank, world)
+    if dp:      # the global token count rides with the batch (one host-side all-reduce inside the prefetch thread)
+        batches = with_global_counts(batches, eos, host_group)
+    stream = pipe(pinned(batches), A.prefetch)
     os.makedirs(P.log, exist_ok=True)
     os.makedirs(P.ckpt, exist_ok=True)
     log = open(pform(P.log, A.trial, '.jsonl'), 'a') if rank == 0 else None
-    eos = vocab.eos_id()
     for _ in range(A.rounds):
         for _ in range(A.steps_per_round // A.valid_every):
             t0 = time.perf_counter()
             for _ in range(A.valid_every):
-                src, tgt = next(stream)
                 if dp:      # this rank's shard; the ELBO means are over the GLOBAL token / row counts (model.py:181,184)
-                    n_glob = global_token_count(int((tgt != eos).sum()) + len(tgt), device=model.device)
+                    src, tgt, n_glob = next(stream)
                     dp.train_step(src, tgt, n_glob, float(T.batch_train))
                 else:
+                    src, tgt = next(stream)
                     model.train_step(src, tgt)
             lg, lk, lo = model.losses()
             dt = time.perf_counter() - t0
             step = model.step
+            errt, vgen, vkld = summ(model, valid, T.batch_valid, rank, world, host_group)      # every rank: its share of the chunks
             if rank == 0:
-                errt, vgen, vkld = summ(model, valid, T.batch_valid)
                 rec = dict(step=step, step_errt=errt, step_loss_gen=vgen, step_loss_kld=vkld,
                            train_loss_gen=lg, train_loss_kld=lk, sentences_per_sec=A.valid_every * T.batch_train / dt)
                 log.write(json.dumps(rec) + "\n")

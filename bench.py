@@ -11,8 +11,8 @@ Workload at every N: BASELINE.json configs[1] per GPU -- fp32, batch 256 x seq 6
 dim_emb 512, latent 128, 3 layers (weak scaling: the per-GPU batch is fixed, global batch 256 N).
 
 Extra objects on the JSON line (N = 1, rank 0):
-  roofline      the kernel class with the largest share of the step, its algorithmic FLOPs per launch
-                divided by its mean launch duration from HIP events recorded on the launch stream
+  roofline      the kernel class with the largest share of the step, its EXECUTED FLOPs per launch (2MNK, a GEMM
+                whose row count is a device-side count priced at that count) divided by its mean launch duration from HIP events recorded on the launch stream
                 during the timed steps, against the fp32 MFMA peak (157.3 TFLOP/s).
   cpu_baseline  the torch-CPU restatement (oracle/vae_torch.py, "port": the reference's TF graph has
                 a GPU-only CudnnGRU and TensorFlow is absent) timed on a bounded sample.
@@ -31,7 +31,7 @@ B, S = 256, 64
 PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA = 2500.0    # TFLOP/s dense (same table)
 STAMP_EVERY = 8            # every n-th timed step carries the per-launch HIP-event stamps of the roofline leg
-PMC_TAG = 'r02'            # the committed rocprofv3 --pmc passes `traffic` / `mfma_busy` are read from
+PMC_TAG = 'r03'            # the committed rocprofv3 --pmc passes `traffic` / `mfma_busy` are read from
 
 
 def host_cores():
@@ -77,7 +77,7 @@ def cpu_baseline(steps=5, warmups=2):
                        "absent and CudnnGRU is GPU-only) on the full %d x %d FULL batch of the headline workload" % (steps, warmups, b, s))
 
 
-def side_config(label, dtype, b, s, steps=3, warmup=2):
+def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None):
     """one of the other BASELINE configurations on this GPU, a few steps, with its kernel-class split (HIP events)"""
     import torch
     from argsim_amd import synth
@@ -106,6 +106,14 @@ def side_config(label, dtype, b, s, steps=3, warmup=2):
                        for k, v in tm.items()},
            "gemm_frac_of_peak": (tm['gemm'][2] / (tm['gemm'][0] * 1e-3) / 1e12 / peak) if tm['gemm'][0] > 0 else None,
            "gemm_peak_tflops": peak}
+    if pmc:        # the committed rocprofv3 --pmc passes of THIS configuration (scripts/profile_round.sh), per GEMM-class launch
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles/%s_%s_pmc_summary.json' % (PMC_TAG, pmc))))
+            out["traffic"] = pm['gemm_class']['hbm_bytes_per_dispatch']
+            out["mfma_busy"] = pm['gemm_class'].get('mfma_busy')
+            out["traffic_unit"] = "HBM bytes per GEMM-class launch, from the committed PMC passes profiles/%s_%s_pmc_summary.json (not measured by this run)" % (PMC_TAG, pmc)
+        except Exception:
+            out["traffic"] = out["mfma_busy"] = None
     m.close()
     del m, ids
     torch.cuda.empty_cache()
@@ -261,6 +269,23 @@ def main():
                                "share_of_step": ms / total_ms,
                                "classes": {k: {"ms_per_step": v[0] / nst, "launches_per_step": v[1] / nst,
                                                "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0)} for k, v in tm.items()}}
+            us, ut = model.present_ids()
+            if us > 0 or ut > 0:
+                # the speed of this line depends on id multiplicity: the first encoder / decoder layer project only the ids
+                # PRESENT in the batch (exact algebra, parity-tested) -- stated with the rate without it
+                out["config"]["present_ids"] = {"src": us, "tgt": ut, "tokens_src": B * S, "tokens_tgt": B * (S + 1), "vocab": CFG['dim_tgt']}
+                model.set_option('table_l1', 0)
+                for i in range(2):
+                    one(10 ** 6 + i)
+                fence()
+                t1 = time.perf_counter()
+                for i in range(A.steps):
+                    one(10 ** 6 + 2 + i)
+                fence()
+                dt1 = time.perf_counter() - t1
+                model.set_option('table_l1', 1)
+                out["table_l1_0"] = {"value": B * A.steps / dt1, "unit": "sentences/sec", "ms_per_step": 1e3 * dt1 / A.steps,
+                                     "what": "same workload with a per-token input projection in the first encoder / decoder layer (option table_l1 = 0)"}
             if not A.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         if world == 1 and A.dtype == 'f32' and not A.no_alt and headline:
@@ -291,7 +316,7 @@ def main():
                 pass
             torch.cuda.empty_cache()
             out["configs"] = {
-                "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 operands in the GEMMs and the GRU recurrence (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128),
+                "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 operands in the GEMMs and the GRU recurrence (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128, pmc='configs2'),
                 "configs[3]/gpu": side_config("BASELINE configs[3] per-GPU load: fp32, batch 1024 (global 8192 over 8 GPUs), seq_len 64; the all-reduce is not part of it", 'f32', 1024, 64),
             }
         print(json.dumps(out))

@@ -111,6 +111,15 @@ int  avae_get_losses(avae_handle h, float out[3]);
 enum { AVAE_HOOK_FENCE = -1 };
 typedef void (*avae_grad_hook)(void* user, int bucket, int64_t offset, int64_t count);
 int  avae_set_grad_hook(avae_handle h, avae_grad_hook hook, void* user);
+/* The buckets the hook speaks of: contiguous ranges of the flat gradient buffer, indexed in buffer order
+ *   0 decode/out | 1..L decode/rnn/lL..l1 | L+1 latent/* | L+2..2L+1 encode/rnnL..rnn1 | 2L+2 embed/embedding
+ * (src/model.py:108-168 variable scopes).  ANNOUNCEMENT order within a step is fixed and does not depend on
+ * the batch shape -- ranks whose shards differ in width pair their collectives by call order:
+ *   0, 1, .., 2L (encode/rnn2), 2L+2 (embedding), 2L+1 (encode/rnn1)
+ * i.e. buffer order except that the embedding bucket, complete once the first encoder layer's input gradient is
+ * scattered, goes out before that layer's weight-gradient GEMMs and overlaps them.                               */
+int  avae_bucket_count(avae_handle h);
+int  avae_bucket_info(avae_handle h, int i, int64_t* offset, int64_t* count);
 
 /* ---- validation: (errt_samp, loss_gen_samp, loss_kld_samp)  (src/train.py:109-110) ------ */
 /* mode 'valid': no word dropout, z = mu.  outputs: errt_samp,loss_gen_samp (>= B*(S_tgt+1))

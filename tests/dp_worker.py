@@ -24,8 +24,10 @@ def main():
     ids, keep, eps = case['ids'], case['keep'], case['eps']
     lo, hi = shard_rows(len(ids), rank, world)
     n_glob = float((ids != 1).sum() + len(ids))
+    mine = ids[lo:hi]
+    width = max(int((mine != 1).sum(1).max()), 1)      # VAE trims a shard to ITS longest row: ranks differ in width
     for i in range(int(case['steps'])):
-        dp.train_step(ids[lo:hi], ids[lo:hi], n_glob, float(len(ids)), keep_mask=keep[:, lo:hi], eps=eps[lo:hi])
+        dp.train_step(mine, mine, n_glob, float(len(ids)), keep_mask=keep[:width, lo:hi], eps=eps[lo:hi])
     torch.cuda.synchronize()
     if rank == 0:
         np.savez(out, **{k.replace('/', '|'): v for k, v in m.get_params().items()})

@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from helpers import CASES, PROD_CASES, make_case  # noqa: E402
+from helpers import BIG_CASES, CASES, PROD_CASES, big_extras, make_case  # noqa: E402
 from oracle import vae_numpy as vn  # noqa: E402
 from oracle import vae_torch as vt  # noqa: E402
 
@@ -37,13 +37,20 @@ def probe(name, shape):
 
 
 # production geometry: only reduced outputs (loss, mu, per-variable gradient norm and one projection each)
-for name in (sys.argv[1:] or PROD_CASES):
-    if name not in PROD_CASES:
-        continue
+# (BIG_CASES, round 3: PIPE kernels at B = 512, R = 1024 / 512 through backward, the bench batch itself -- minutes of
+#  float64 autograd each; only written when named on the command line or with --big)
+big = [n for n in BIG_CASES if n in sys.argv[1:] or '--big' in sys.argv[1:]]
+for name in ([n for n in sys.argv[1:] if n in PROD_CASES] or ([] if big else list(PROD_CASES))) + big:
     cfg, P, ids, keep, eps = make_case(name)
-    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, 20000, keep, eps)
+    extra = big_extras(name) if name in BIG_CASES else {}
+    outs, grads = vt.loss_and_grads(P, cfg, ids, ids, 20000, keep, eps, **extra)
     o = vn.forward(P, cfg, ids, ids, 'valid')
     out = dict(ids=ids, keep=keep, eps=eps, loss=outs['loss'], loss_gen=outs['loss_gen'], loss_kld=outs['loss_kld'], mu=o['mu'], lv=o['lv'])
+    if name in BIG_CASES:
+        out['loss_gen_samp'] = outs['loss_gen_samp'].astype(np.float32)      # per-token CE of the TRAIN forward (dropout + eps on)
+        out['z'] = outs['z']
+        for k in ('mu', 'lv', 'z'):            # (float32 is 6e-8 relative: far inside the 2e-5 tolerance, half the file)
+            out[k] = out[k].astype(np.float32)
     for k, g in grads.items():
         out['gnorm/' + k] = np.linalg.norm(g)
         out['gdot/' + k] = float((g * probe(k, g.shape)).sum())

@@ -23,21 +23,41 @@ PROD_CASES = {
     'prod64':  (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 64, 64, 'ragged'),
     'prod128': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 64, 128, 'ragged'),
 }
+# round 3: what the BIG configurations run, reduced fixtures only.  Fifth field: extras
+#   prod512  B = 512: every GRU launch is a row-block-pipelined (PIPE) team instantiation, fp32 and bf16 (configs[2]/[3])
+#   cfg0     the reference's own config.json dims (R = 1024, src/config.json:10-21) through backward
+#   cfg4     BASELINE configs[4]: R = 512 with the beta / free-bits extension live
+#   headline the bench batch itself: B 256 x S 64 FULL Zipf ids of argsim_amd.synth (seed 0), step 20000
+BIG_CASES = {
+    'prod512':  (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 512, 14, 'ragged', {}),
+    'cfg0':     (dict(dim_tgt=8192, dim_emb=512, dim_rep=1024, rnn_layers=3), 32, 64, 'ragged', {}),
+    'cfg4':     (dict(dim_tgt=8192, dim_emb=512, dim_rep=512, rnn_layers=3), 64, 32, 'ragged', dict(kl_beta=0.5, free_bits=0.02)),
+    'headline': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 256, 64, 'synth', {}),
+}
+
+
+def big_extras(name):
+    return dict(BIG_CASES[name][4])
 
 
 def make_case(name, seed=0, pad=2, bias_scale=0.1):
-    kw, B, S, lens = (CASES.get(name) or PROD_CASES[name])
+    kw, B, S, lens = (CASES.get(name) or PROD_CASES.get(name) or BIG_CASES[name][:4])
     cfg = vn.make_cfg(**kw)
     rng = np.random.default_rng(seed + 17)
     V, R = cfg['dim_tgt'], cfg['dim_rep']
     ids = np.full((B, S + pad), cfg['eos'], np.int32)
     if lens is None:
         lens = [S] * B
-    elif isinstance(lens, str):        # 'ragged': a few full rows, a length-1 row, the rest uniform in [2, S]
+    elif lens == 'ragged':             # a few full rows, a length-1 row, the rest uniform in [2, S]
         lens = rng.integers(2, S + 1, B)
         lens[[0, B // 2]] = S
         lens[1] = 1
-    for b, n in enumerate(lens):
+    if isinstance(lens, str) and lens == 'synth':      # the bench batch (FULL Zipf rows), eos-padded like every other case
+        from argsim_amd import synth
+        ids[:, :S] = synth.batch(B, S, V, seed=0)
+        lens = [S] * B
+    else:
+      for b, n in enumerate(lens):
         ids[b, :n] = rng.integers(3, V, n)
     smax = max(lens)
     keep = (rng.random((smax, B)) < 0.6).astype(np.uint8)

@@ -191,3 +191,62 @@ def test_rccl_path_puts_every_collective_into_the_side_streams_order(monkeypatch
     assert not g.stream_ordered and len(g.pending) == 1 and ('comm', 'work.wait') not in log
     g.fence()
     assert not g.pending and ('main', 'work.wait') in log and log[-1] == ('main', 'wait_stream', 'comm')
+
+
+# ------------------------------------------------------------------------------------------ round 3: host-side scalars
+class _EvalStub:
+    """model.eval of the training driver on the host: per-token error / CE and per-element KL that depend only on the ids"""
+    def eval(self, src, tgt):
+        n = int((tgt != 1).sum() + len(tgt))
+        r = np.random.default_rng(int(tgt.sum()))
+        return (r.random(n) < 0.3).astype(np.float32), r.random(n).astype(np.float32), r.random((len(tgt), 4)).astype(np.float32)
+
+
+def _host_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    host = dist.new_group(backend='gloo')
+    from argsim_amd.dist import shard_rows
+    from argsim_amd.train import pipe, summ, with_global_counts
+    rng = np.random.default_rng(5)
+    glob = []
+    for _ in range(6):
+        ids = np.ones((8, 10), np.int32)
+        for b in range(8):
+            n = int(rng.integers(1, 11)); ids[b, :n] = rng.integers(3, 50, n)
+        glob.append(ids)
+    lo, hi = shard_rows(8, rank, world)
+    shards = ((g[lo:hi], g[lo:hi]) for g in glob)
+    # the count rides with the batch and is computed inside the prefetch thread (as train.main wires it)
+    got = [n for _, _, n in pipe(with_global_counts(shards, 1, host), 4)]
+    want = [float((g != 1).sum() + len(g)) for g in glob]
+    valid = np.concatenate(glob)
+    mine = summ(_EvalStub(), valid, 5, rank, world, host)
+    if rank == 0:
+        torch.save({'got': got, 'want': want, 'summ': mine}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_host_side_token_counts_and_sharded_validation(tmp_path):
+    """train.py under data parallelism: N_global is one host-side (gloo) all-reduce per batch issued from the prefetch
+    thread -- no device scalar is read back in the training loop -- and validation chunks are dealt over the ranks with
+    the sums added across them: the same three means as one process over the whole array (src/train.py:104-113)."""
+    out = str(tmp_path / 'h.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_host_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert got['got'] == got['want']
+    from argsim_amd.train import summ
+    rng = np.random.default_rng(5)
+    glob = []
+    for _ in range(6):
+        ids = np.ones((8, 10), np.int32)
+        for b in range(8):
+            n = int(rng.integers(1, 11)); ids[b, :n] = rng.integers(3, 50, n)
+        glob.append(ids)
+    one = summ(_EvalStub(), np.concatenate(glob), 5)
+    assert np.allclose(got['summ'], one, rtol=1e-6, atol=0)

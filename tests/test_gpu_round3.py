@@ -1,0 +1,200 @@
+"""GPU tests added in round 3: a batch-shape-independent order of data-parallel bucket announcements, oracle fixtures for
+what the BIG configurations run (row-block-pipelined kernels at B = 512, R = 1024 / 512 through backward, the bench batch
+itself), executed-FLOP accounting of the timing hook."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import big_extras, make_case
+from oracle import vae_numpy as vn
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KEYS = ('dim_tgt', 'dim_emb', 'dim_rep', 'rnn_layers', 'accelerate', 'learn_rate', 'bos', 'eos')
+
+
+def _vae(cfg, P, mode='train', **kw):
+    from argsim_amd.model import VAE
+    m = VAE(mode, init=False, **{k: cfg[k] for k in KEYS}, **kw)
+    m.set_params(P)
+    return m
+
+
+def _probe(name, shape):
+    import zlib
+    return np.random.default_rng(zlib.crc32(name.encode())).standard_normal(shape)
+
+
+def _gold(name):
+    with np.load(os.path.join(HERE, 'golden', 'oracle_%s.npz' % name), allow_pickle=False) as f:
+        return {k: f[k] for k in f.files}
+
+
+# ------------------------------------------------------------------------------------------ bucket order
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_bucket_announcement_order_does_not_depend_on_the_batch_shape(L):
+    """Data-parallel ranks pad their shards to their own longest row, so within ONE step a rank can be table-fed
+    (tokens >= vocabulary) while its peer is not; collectives are paired by call order, so the hook must
+    announce buckets in one fixed order whatever the shape: 0..2L, then the embedding (2L+2), then encode/rnn1 (2L+1),
+    with one fence before each of the 2L persistent-capable BPTT launches."""
+    from argsim_amd.model import VAE
+    V = 64
+    m = VAE('train', dim_tgt=V, dim_emb=64, dim_rep=16, rnn_layers=L, seed=0)
+    m.step = 20000
+    want = list(range(2 * L + 1)) + [2 * L + 2, 2 * L + 1]
+    rng = np.random.default_rng(3)
+    seen = {}
+    # (B, S): both id sources table-fed | neither | only the decoder's (S*B < V <= (S+1)*B) | one token per row
+    for B, S in ((12, 10), (4, 6), (7, 9), (3, 1)):
+        ids = rng.integers(3, V, (B, S)).astype(np.int32)
+        log = []
+        m.set_grad_hook(lambda b, off, cnt: log.append(b))
+        m.forward_backward(ids, ids, seed=1)
+        m.set_grad_hook(None)
+        assert all(np.isfinite(m.losses()))
+        assert [b for b in log if b >= 0] == want, (B, S, log)
+        assert log.count(-1) == 2 * L and log[0] == -1, (B, S, log)
+        seen[(B, S)] = m.present_ids()
+    assert seen[(12, 10)][0] > 0 and seen[(12, 10)][1] > 0          # table-fed both sides
+    assert seen[(4, 6)] == (-1, -1) and seen[(7, 9)][0] == -1 and seen[(7, 9)][1] > 0
+    m.close()
+
+
+def test_two_ranks_whose_shards_straddle_the_table_threshold(tmp_path):
+    """The same, end to end: two real ranks on the test GPU over gloo; rank 0's shard (96 + 104 tokens, V = 64) is
+    table-fed, rank 1's (rows of at most 5 ids) is not.  Before the fix the two ranks paired the embedding all-reduce with
+    an encoder-layer all-reduce of another size.  Must reproduce the single-process parameters."""
+    import subprocess
+    import sys
+    from argsim_amd.model import VAE
+    V, D, R, B, S, steps = 64, 64, 16, 16, 12, 2
+    rng = np.random.default_rng(11)
+    lens = rng.integers(2, S + 1, B); lens[0] = S
+    lens[B // 2:] = rng.integers(1, 6, B - B // 2)
+    ids = np.ones((B, S), np.int32)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(3, V, n)
+    keep = (rng.random((S, B)) < 0.8).astype(np.uint8)
+    eps = rng.standard_normal((B, R)).astype(np.float32)
+    case, out = str(tmp_path / 'case.npz'), str(tmp_path / 'dp.npz')
+    np.savez(case, V=V, D=D, R=R, ids=ids, keep=keep, eps=eps, steps=steps)
+    port = 29500 + (os.getpid() % 400)
+    root = os.path.dirname(HERE)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), case, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    m = VAE('train', dim_tgt=V, dim_emb=D, dim_rep=R, rnn_layers=3, seed=0)
+    m.step = 20000
+    for i in range(steps):
+        m.train_step(ids, ids, keep_mask=keep, eps=eps)
+    ref = m.get_params()
+    got = {k.replace('|', '/'): v for k, v in np.load(out).items()}
+    worst = max(float(np.abs(got[k] - ref[k]).max()) for k in ref)
+    assert worst <= 2e-6, worst
+
+
+# ------------------------------------------------------------------------------------------ fixtures of the big configurations
+def _check_against_fixture(name, dtype, tz, tl, tg, check_adam=False, **vae_kw):
+    gold = _gold(name)
+    cfg, P, ids, keep, eps = make_case(name)
+    assert np.array_equal(ids, gold['ids']) and np.array_equal(keep, gold['keep'])
+    extra = big_extras(name)
+    m = _vae(cfg, P, dtype=dtype, **extra, **vae_kw)
+    m.step = 20000
+    z, lv = m.encode(ids, return_lv=True)
+    assert np.abs(z - gold['mu']).max() <= tz and np.abs(lv - gold['lv']).max() <= tz, (name, dtype)
+    p0 = m.params.clone()
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    lg, lk, lo = m.losses()
+    for got, key in ((lo, 'loss'), (lg, 'loss_gen'), (lk, 'loss_kld')):
+        assert abs(got - float(gold[key])) <= tl * abs(float(gold[key])) + 1e-7, (name, dtype, key, got, float(gold[key]))
+    grads = m.get_grads()
+    for k, g in grads.items():
+        g = g.astype(np.float64)
+        n = float(gold['gnorm/' + k])
+        assert abs(np.linalg.norm(g) - n) <= tg * n, (name, dtype, k)
+        p = _probe(k, g.shape)
+        assert abs(float((g * p).sum()) - float(gold['gdot/' + k])) <= tg * n * np.linalg.norm(p), (name, dtype, k)
+    if check_adam:
+        # the update kernel against the oracle's TF-style Adam applied to the SAME (device) gradient: m = v = 0, the
+        # beta powers at step + 1 (avae_adam_step), epsilon outside the bias-corrected square root (model.py:189)
+        import torch
+        g = m.grads.clone()
+        lr = vn.schedule(20000, cfg['accelerate'], cfg['learn_rate'])[2]
+        m.adam_step()
+        newp, _, _ = vn.adam_tf({'p': p0.double().cpu().numpy()}, {'p': g.double().cpu().numpy()},
+                                {'p': 0.0}, {'p': 0.0}, 20000, lr)
+        d = np.abs(m.params.double().cpu().numpy() - newp['p']).max()
+        assert d <= 2e-6, d          # |update| ~ 1.3e-3 per element; fp32 rounding of p - lr_t m / (sqrt(v) + eps)
+        assert m.step == 20001
+        del torch
+    m.close()
+    return gold
+
+
+@pytest.mark.parametrize("dtype,tz,tl,tg", [('f32', 2e-5, 2e-5, 2e-4), ('bf16', 3e-2, 1e-2, 5e-2)])
+def test_row_block_pipelined_kernels_against_the_oracle_fixture(dtype, tz, tl, tg):
+    """B = 512 (S = 14, ragged, D 512, V 8192): every GRU launch of the default path is a PIPE team instantiation -- what
+    configs[2] (bf16) and configs[3] (fp32) run -- compared with the float64 oracle fixture ONLY: loss, mu, log sigma^2,
+    per-variable gradient norm and one fixed projection of every gradient."""
+    _check_against_fixture('prod512', dtype, tz, tl, tg)
+
+
+def test_reference_config_dims_through_backward_and_adam():
+    """src/config.json:10-21 dims (R = 1024) at B = 32, S = 64 ragged: the latent block's thin / paired / split-K GEMM
+    shaping keyed on R, through backward and one Adam update."""
+    _check_against_fixture('cfg0', 'f32', 2e-5, 2e-5, 2e-4, check_adam=True)
+
+
+def test_configs4_latent512_beta_free_bits_against_the_oracle_fixture():
+    """BASELINE configs[4]: R = 512 at D 512 / V 8192 with kl_beta = 0.5 and free_bits = 0.02 live (extensions: identity at
+    (1, 0)), through backward and one Adam update, against the extended float64 oracle's fixture."""
+    _check_against_fixture('cfg4', 'f32', 2e-5, 2e-5, 2e-4, check_adam=True)
+
+
+def test_headline_batch_against_the_oracle_fixture():
+    """The bench batch itself -- B 256 x S 64 FULL Zipf ids (argsim_amd.synth seed 0), step 20000, table-fed first layers,
+    4-team encoder and 2-team decoder kernels, every GEMM form of the headline step -- against the float64 oracle's
+    fixture: loss, mu, per-token CE, gradient norms and projections."""
+    gold = _check_against_fixture('headline', 'f32', 2e-5, 2e-5, 2e-4)
+    cfg, P, ids, keep, eps = make_case('headline')
+    m = _vae(cfg, P)
+    m.step = 20000
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    assert m.present_ids()[0] > 3000                    # the table-fed path really ran
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------ executed-FLOP accounting
+def test_timing_hook_counts_executed_flops_of_device_count_gemms():
+    """avae_timing_collect priced the table-fed layers' GEMMs at their static 8192-row bound although the
+    kernels exit at the number of ids present.  The class total must now fall with the present-id count: the same batch
+    with table_l1 = 0 (per-token GEMMs, no device counts on those layers) executes MORE FLOPs, by what the table saves:
+    3 x 2 (tokens - U) D 3D per direction of the two first layers."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    B, S, D, V = 256, 64, 512, 8192
+    ids = synth.batch(B, S, V, seed=0)
+    m = VAE('train', seed=0, dim_tgt=V, dim_emb=D, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    fl = {}
+    for tab in (1, 0):
+        m.set_option('table_l1', tab)
+        m.train_step(ids, ids, seed=1)
+        m.set_option('timing', 1)
+        m.train_step(ids, ids, seed=2)
+        fl[tab] = m.timing_collect()['gemm'][2]
+        m.set_option('timing', 0)
+        if tab:
+            us, ut = m.present_ids()
+    assert 0 < us < V and 0 < ut < V
+    T = S + 1
+    saved = 3 * 2.0 * D * 3 * D * (2 * (B * S - us) + (B * T - ut))       # fwd + two backward GEMMs; encoder has two directions
+    assert abs((fl[0] - fl[1]) - saved) <= 0.02 * saved, (fl, saved, us, ut)
+    m.close()
