@@ -1718,6 +1718,52 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ one step from a zero state
+// The top encoder layer's backward direction (model.py:119-121,135): the only consumer of that layer's output is the pick at
+// position len_b - 1, where the reversed direction has seen exactly ONE token -- its first step, from h = 0.  Every later step
+// of that direction is dead in the reference's graph (never reaches z or the loss, zero gradient: dR of that direction is
+// exactly zero), so the build runs that one step only: the cell of gru_cell with R h = 0, i.e. gh = bR, for B rows.
+// gi (B, 3D) and bR in G16 order; h goes to h_out[b * ldo + j]; sv (B, D/16, 16, 4) keeps r, u, n, hn for the backward.
+__global__ __launch_bounds__(256) void gru_first_step_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ bR, float* __restrict__ h_out,
+                                                                 int ldo, float* __restrict__ sv, int B, int D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, j = i - b * D, c = (j >> 4) * 48 + (j & 15) * 3;
+    const float* g = gi + (size_t)b * 3 * D + c;
+    const GruCellOut cell = gru_cell(g[0], g[1], g[2], bR[c], bR[c + 1], bR[c + 2], 0.f);
+    h_out[(size_t)b * ldo + j] = cell.h;
+    if (sv) *reinterpret_cast<float4*>(sv + ((size_t)b * D + j) * 4) = make_float4(cell.r, cell.u, cell.n, bR[c + 2]);
+}
+hipError_t gru_first_step_fwd(hipStream_t st, const float* gi, const float* bR, float* h_out, int ldo, float* sv, int B, int D)
+{
+    hipLaunchKernelGGL(gru_first_step_fwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, gi, bR, h_out, ldo, sv, B, D);
+    return hipGetLastError();
+}
+// its BPTT: dH = dh (nothing carried), h_prev = 0 -- the formulas of gru_bwd_team_kernel's gate phase.  dgi = [dr, du, dn],
+// dgh = [dr, du, dn r], both (B, 3D) in G16 column order.
+__global__ __launch_bounds__(256) void gru_first_step_bwd_kernel(const float* __restrict__ dh, int ldd, const float* __restrict__ sv,
+                                                                 float* __restrict__ dgi, float* __restrict__ dgh, int B, int D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, j = i - b * D, c = (j >> 4) * 48 + (j & 15) * 3;
+    const float4 s = *reinterpret_cast<const float4*>(sv + ((size_t)b * D + j) * 4);
+    const float dH = dh[(size_t)b * ldd + j];
+    const float r_ = s.x, u = s.y, nn = s.z;
+    const float dn = dH * (1.f - u) * (1.f - nn * nn);
+    const float du = dH * (0.f - nn) * u * (1.f - u);
+    const float dr = dn * s.w * r_ * (1.f - r_);
+    float* a = dgi + (size_t)b * 3 * D + c; float* g = dgh + (size_t)b * 3 * D + c;
+    a[0] = dr; a[1] = du; a[2] = dn;
+    g[0] = dr; g[1] = du; g[2] = dn * r_;
+}
+hipError_t gru_first_step_bwd(hipStream_t st, const float* dh, int ldd, const float* sv, float* dgi, float* dgh, int B, int D)
+{
+    hipLaunchKernelGGL(gru_first_step_bwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, dh, ldd, sv, dgi, dgh, B, D);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------ launchers
 constexpr int kGruSyncWords = 64 + 64 + 1536;   // (spare) | detection counters | XCD ids (njobs*G*HT)
 bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 512; }

@@ -92,6 +92,11 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
 bool gru_forward_uses_team(const GruArgs& a, bool persistent);      // true: the launch runs the LDS-weight team kernels (gi_rows honoured)
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
 bool gru_dim_supported(int D);
+// one GRU step from a zero state for B rows (the top encoder layer's backward direction: gru.hip "one step from a zero
+// state"): gi (B, 3D) / bR G16; h -> h_out[b * ldo + j]; sv (B, D, 4) = r, u, n, hn or nullptr
+hipError_t gru_first_step_fwd(hipStream_t st, const float* gi, const float* bR, float* h_out, int ldo, float* sv, int B, int D);
+// its backward: dh[b * ldd + j] -> dgi, dgh (B, 3D) G16
+hipError_t gru_first_step_bwd(hipStream_t st, const float* dh, int ldd, const float* sv, float* dgi, float* dgh, int B, int D);
 bool gru_diag_build();     // true: built with -DAVAE_DIAG (ablation / stamp instantiations present)
 
 // ---------------------------------------------------------------- small kernels (ops.hip)
@@ -136,6 +141,8 @@ hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32
 hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D);
 // h[b,:] = hs[(len_b-1)*B + b, :]  (model.py:135)
 hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W);
+// dhs[(len_b-1)*B+b,:] += d[b,:]
+hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W);
 // dhs = 0 everywhere except dhs[(len_b-1)*B+b,:] = dh[b,:]
 hipError_t pick_last_bwd(hipStream_t st, float* dhs, const float* dh, const int32_t* lens, int S, int B, int W);
 

@@ -49,6 +49,7 @@ struct avae_ctx {
     int persistent = 1;
     bool first_step_checked = false;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
     // offsets
@@ -122,6 +123,7 @@ struct Ws {
     std::vector<float*> e_gi, e_hs, e_sv[2], e_hp[2];
     std::vector<float*> d_gi, d_hd, d_sv, d_hp;
     float *hpick, *mu, *lv, *z, *eps, *kld, *h0;
+    float *xlast, *gib, *svb, *dgib, *dghb, *dxl;     // one-step top backward direction (top_one_step): (B,2D) (B,3D) (B,D,4) (B,3D) (B,3D) (B,2D)
     float *hc, *ho, *logits;
     float *loss_samp, *errt_samp;
     // backward
@@ -189,6 +191,8 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.xbuf = b.take<float>(w.xbuf_floats);
     }
     w.hpick = b.take<float>((size_t)B * 2 * D);
+    w.xlast = b.take<float>((size_t)B * 2 * D); w.gib = b.take<float>((size_t)B * 3 * D); w.svb = b.take<float>((size_t)B * 4 * D);
+    w.dgib = b.take<float>(train ? (size_t)B * 3 * D : 0); w.dghb = b.take<float>(train ? (size_t)B * 3 * D : 0); w.dxl = b.take<float>(train ? (size_t)B * 2 * D : 0);
     w.mu = b.take<float>((size_t)B * R); w.lv = b.take<float>((size_t)B * R); w.z = b.take<float>((size_t)B * R);
     w.eps = b.take<float>((size_t)B * R); w.kld = b.take<float>((size_t)B * R);
     w.h0 = b.take<float>((size_t)B * D);
@@ -399,6 +403,13 @@ Sched schedule(const avae_ctx* h)
     return s;
 }
 
+// The top encoder layer's backward direction is consumed at ONE position only -- the pick at len_b - 1 (model.py:135), the
+// first step of the reversed sequence, from h = 0: its other S - 1 steps, their input projection and their whole BPTT are
+// dead in the reference's graph (zero gradient; dR of that direction is exactly 0, oracle fixtures gnorm/encode/rnnL/bwd/R).
+// The build computes that one step for B rows (gru_first_step_*) and runs the layer's GRU launches with the forward
+// direction alone.  Same values as the full form (option enc_top1 = 0), a sixth of the encoder's work not executed.
+static bool top_one_step(const avae_ctx* h) { return h->enc_top1 && h->cfg.rnn_layers >= 2; }
+
 // -------------------------------------------------------------------------------- forward pieces
 int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 {
@@ -410,23 +421,24 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
     const float* x = w.emb_src; int In = D;
     for (int i = 0; i < L; ++i) {
         const GruP& p = h->enc[i];
+        const bool top1 = i == L - 1 && top_one_step(h);      // forward direction only; the backward direction's one live step follows the loop
         if (i == 0 && table) {
             const int32_t* cnt = id_groups_count(w.grp_src, rs, V);
             AV_CHECK(id_groups_build(h->stream, w.src_tm, rs, V, w.grp_src, save));
             AV_CHECK(rows_gather(h->stream, w.emb_src, h->P + h->oE, id_groups_uid(w.grp_src, rs, V), cnt, std::min(V, rs), D));
             AV_TRY(gemm(h, false, false, w.emb_src, D, h->P + p.W, D, w.ew, 6 * D, std::min(V, rs), 6 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
         } else
-        AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, 6 * D, In, 1.f, h->P + p.bW));
+        AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, h->P + p.bW));
         GruArgs a{};
-        a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
-        gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
+        a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
+        gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         // table-fed layer: the team kernels read gi straight out of the per-id projection through a row index per token;
         // the other kernel forms get a per-token copy
         const bool table0 = i == 0 && table, indirect = table0 && gru_forward_uses_team(a, h->persistent != 0);
         if (indirect) AV_CHECK(rank_rows(h->stream, w.tokrow_src, w.src_tm, id_groups_rank(w.grp_src, rs, V), rs, V));
         else if (table0) AV_CHECK(rows_gather_ranked(h->stream, w.e_gi[0], w.ew, w.src_tm, id_groups_rank(w.grp_src, rs, V), rs, 6 * D, V));
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < a.njobs; ++d) {
             GruJob& j = a.job[d];
             j.gi = (indirect ? w.ew : w.e_gi[i]) + d * 3 * D;
             j.gi_rows = indirect ? w.tokrow_src : nullptr;
@@ -438,11 +450,19 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             j.hp = save ? w.e_hp[d][i] : nullptr;
             j.reverse = d;
         }
-        { Timed t(h, 1, 2.0 * 2 * Ss * (double)B * D * 3 * D);
+        { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
+        if (top1) {
+            // the backward direction at position len_b - 1: gi = W_b x[len_b - 1] + bW_b for B rows, then one cell step from h = 0
+            const int64_t oWb = p.W + (int64_t)3 * D * In;
+            AV_CHECK(pick_last(h->stream, w.xlast, x, w.lens_src, B, In));
+            AV_TRY(gemm(h, false, false, w.xlast, In, h->P + oWb, In, w.gib, 3 * D, B, 3 * D, In, 1.f, h->P + p.bW + 3 * D));
+        }
         x = w.e_hs[i]; In = 2 * D;
     }
     AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D));
+    if (top_one_step(h))      // (the pick copied the never-written backward half of the top layer's rows: overwritten here)
+        AV_CHECK(gru_first_step_fwd(h->stream, w.gib, h->P + h->enc[L - 1].bR + 3 * D, w.hpick + D, 2 * D, save ? w.svb : nullptr, B, D));
     return 0;
 }
 
@@ -647,11 +667,20 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     for (int i = L - 1; i >= 0; --i) {
         const GruP& p = h->enc[i];
         const int In = i == 0 ? D : 2 * D;
+        const bool top1 = i == L - 1 && top_one_step(h);
+        const int64_t oWb = p.W + (int64_t)3 * D * In;
+        if (top1) {
+            // backward direction of the top layer: BPTT of its one live step (dH = the pick's gradient, nothing carried),
+            // bias gradients = column sums over the B rows; dR of this direction stays exactly zero (h_prev = 0)
+            AV_CHECK(gru_first_step_bwd(st, w.dhpick + D, 2 * D, w.svb, w.dgib, w.dghb, B, D));
+            AV_CHECK(colsum(st, w.dgib, B, 3 * D, 3 * D, G + p.bW + 3 * D, nullptr));
+            AV_CHECK(colsum(st, w.dghb, B, 3 * D, 3 * D, G + p.bR + 3 * D, nullptr));
+        }
         GruArgs a{};
-        a.njobs = 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
-        gru_geometry(D, 2, B, &a.G, &a.rows_per_group);
+        a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
+        gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < a.njobs; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
             j.dh_out = w.dhs[cur] + d * D; j.dgi = w.dgi_e + d * 3 * D; j.dgh = w.dgh_e + d * 3 * D;
@@ -659,7 +688,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
         hook_fence(h);
-        { Timed t(h, 2, 2.0 * 2 * (Ss - 1) * (double)B * D * 3 * D);
+        { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
         const bool table = i == 0 && use_table(h, rs);
@@ -688,14 +717,22 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
                 AV_TRY(gemm_tn_grad(h, w.dew, 6 * D, w.emb_src, D, G + p.W, D, 6 * D, D, U, 1.f, cnt));
             } else
             AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
+        } else if (top1) {
+            AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 3 * D, In, rs));                  // forward direction's W
+            AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));              // backward direction's: B rows
         } else
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
-        {   // dR of the two directions: same shape, one launch
+        if (top1) AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs));
+        else {   // dR of the two directions: same shape, one launch
             const Pair bwd{w.dgh_e + 3 * D, w.e_hp[1][i], G + p.R + (int64_t)3 * D * D, nullptr};
             AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, nullptr, &bwd));
         }
         if (i > 0)
-        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
+        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, top1 ? 3 * D : 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
+        if (top1) {       // the backward direction's input gradient lands on the rows at len_b - 1
+            AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
+            AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In));
+        }
         cur ^= 1;
         fire_hook(h, 2 + L + (L - 1 - i));
     }
@@ -919,6 +956,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
     if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
+    if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");

@@ -506,6 +506,24 @@ hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* l
     hipLaunchKernelGGL(pick_last_kernel, dim3(B), dim3(256), 0, st, h, hs, lens, B, W);
     return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void pick_last_add_kernel(float* __restrict__ dhs, const float* __restrict__ d,
+                                                            const int32_t* __restrict__ lens, int B, int W)
+{
+    const int b = blockIdx.x;
+    const int t = max(lens[b] - 1, 0);
+    float4* dst = reinterpret_cast<float4*>(dhs + ((size_t)t * B + b) * W);
+    const float4* s = reinterpret_cast<const float4*>(d + (size_t)b * W);
+    for (int c = threadIdx.x; c < W / 4; c += blockDim.x) {
+        float4 v = dst[c]; const float4 a = s[c];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        dst[c] = v;
+    }
+}
+hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W)
+{
+    hipLaunchKernelGGL(pick_last_add_kernel, dim3(B), dim3(256), 0, st, dhs, d, lens, B, W);
+    return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void pick_last_bwd_kernel(float* __restrict__ dhs, const float* __restrict__ dh,
                                                             const int32_t* __restrict__ lens, int S, int B, int W)
 {

@@ -112,7 +112,7 @@ enum { AVAE_HOOK_FENCE = -1 };
 typedef void (*avae_grad_hook)(void* user, int bucket, int64_t offset, int64_t count);
 int  avae_set_grad_hook(avae_handle h, avae_grad_hook hook, void* user);
 /* The buckets the hook speaks of: contiguous ranges of the flat gradient buffer, indexed in buffer order
- *   0 decode/out | 1..L decode/rnn/lL..l1 | L+1 latent/* | L+2..2L+1 encode/rnnL..rnn1 | 2L+2 embed/embedding
+ *   0 decode/out | 1..L decode/rnn/lL..l1 | L+1 latent | L+2..2L+1 encode/rnnL..rnn1 | 2L+2 embed/embedding
  * (src/model.py:108-168 variable scopes).  ANNOUNCEMENT order within a step is fixed and does not depend on
  * the batch shape -- ranks whose shards differ in width pair their collectives by call order:
  *   0, 1, .., 2L (encode/rnn2), 2L+2 (embedding), 2L+1 (encode/rnn1)

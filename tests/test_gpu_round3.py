@@ -198,3 +198,36 @@ def test_timing_hook_counts_executed_flops_of_device_count_gemms():
     saved = 3 * 2.0 * D * 3 * D * (2 * (B * S - us) + (B * T - ut))       # fwd + two backward GEMMs; encoder has two directions
     assert abs((fl[0] - fl[1]) - saved) <= 0.02 * saved, (fl, saved, us, ut)
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ dead steps of the top encoder layer
+@pytest.mark.parametrize("case", ['mid', 'tab', 'prod64'])
+def test_top_layer_backward_direction_one_step_equals_the_full_form(case):
+    """model.py:119-121,135: the top encoder layer's output is consumed at position len_b - 1 only, where the reversed direction
+    has seen ONE token; its other steps never reach z or the loss and carry zero gradient (the oracle's gradient of
+    encode/rnnL/bwd/R is exactly 0).  The default path runs that one step (option enc_top1); the full form (enc_top1 = 0)
+    executes all S steps like the reference's graph: same z, same losses, same gradients -- and dR of that direction exactly
+    zero in both."""
+    cfg, P, ids, keep, eps = make_case(case)
+    m = _vae(cfg, P)
+    m.step = 20000
+    out = {}
+    for top1 in (1, 0):
+        m.set_option('enc_top1', top1)
+        z = m.encode(ids)
+        ev = m.eval(ids, ids)
+        m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+        out[top1] = (z, ev, m.get_grads(), m.losses())
+    L = cfg['rnn_layers']
+    # the forward direction of that layer runs as a one-job launch in the one-step form (another K-split tree): rounding only
+    assert np.abs(out[1][0] - out[0][0]).max() <= 2e-6
+    for a, b in zip(out[1][1][1:], out[0][1][1:]):
+        assert np.abs(a - b).max() <= 2e-5
+    assert abs(out[1][3][2] - out[0][3][2]) <= 2e-6 * abs(out[0][3][2])
+    for k in out[0][2]:
+        a, b = out[1][2][k].astype(np.float64), out[0][2][k].astype(np.float64)
+        if k == 'encode/rnn%d/bwd/R' % L:
+            assert not a.any() and not b.any(), k
+            continue
+        assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b) + 1e-12, k
+    m.close()
