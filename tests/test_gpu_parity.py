@@ -202,15 +202,21 @@ def test_random_draws_are_seeded_and_sane():
     assert abs(a[0] - c[0]) > 1e-4 * abs(a[0])
 
 
-def test_bench_scale_persistent_equals_stepwise():
+@pytest.mark.parametrize("enc_top1", [0, 1])
+def test_bench_scale_persistent_equals_stepwise(enc_top1):
     """BASELINE configs[1] geometry (B=256, S=64, D=512: 512 co-resident workgroups per GRU launch): the
     persistent kernels' in-launch hand-offs must reproduce the one-launch-per-step results bit for bit
-    on the forward (z, per-token CE), and the gradients up to float-atomic summation order."""
+    on the forward (z, per-token CE), and the gradients up to float-atomic summation order.
+    enc_top1 = 0: every encoder launch carries both directions (4-team form, the K split of the one-launch-per-step kernels):
+    z bit for bit.  enc_top1 = 1 (default): the top layer's forward direction is a one-job launch, which at B = 256 runs the
+    2-team form whose K is split over 8 waves -- same products, another summation tree: z to rounding."""
     from argsim_amd import synth
     from argsim_amd.model import VAE
     m = VAE('train', seed=3, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.set_option('enc_top1', enc_top1)
     ids = synth.batch(256, 64, 8192, ragged=True, seed=5)
     m.step = 20000
+    same = np.array_equal if not enc_top1 else (lambda a, b: np.abs(np.asarray(a, np.float64) - b).max() <= 2e-6)
     # every forward-kernel variant (0 generic, 1 item pipeline, 2 four-team LDS-weight kernel) must reproduce
     # the one-launch-per-step encoder bit for bit
     m.set_option('persistent', 0)
@@ -218,7 +224,7 @@ def test_bench_scale_persistent_equals_stepwise():
     m.set_option('persistent', 1)
     for item in (0, 1, 2):
         m.set_option('gru_item', item)
-        assert np.array_equal(m.encode(ids), z_ref), item
+        assert same(m.encode(ids), z_ref), item
     m.set_option('gru_item', 2)
     res = {}
     for mode in (1, 0, 1):
@@ -230,12 +236,15 @@ def test_bench_scale_persistent_equals_stepwise():
         g = m.grads.clone()
         res.setdefault(mode, []).append((z, ev, g))
     (z1, e1, g1), (z0, e0, g0), (z2, e2, g2) = res[1][0], res[0][0], res[1][1]
-    assert np.array_equal(z1, z0) and np.array_equal(z1, z2)
+    assert same(z1, z0) and np.array_equal(z1, z2)
     # decoder layers (one job, B = 256) run the 2-team form whose K is split over 8 waves instead of 4: same products,
     # another summation tree, so per-token CE agrees to rounding (errt and the KL terms, encoder only, exactly)
-    for a, b in zip(e1, e0):
+    for a, b in zip(e1[1:], e0[1:]):
         assert np.allclose(a, b, rtol=0, atol=2e-5)
-    assert np.array_equal(e1[0], e0[0]) and np.array_equal(e1[2], e0[2])
+    if not enc_top1:
+        assert np.array_equal(e1[0], e0[0]) and np.array_equal(e1[2], e0[2])
+    else:
+        assert np.abs(e1[0] - e0[0]).mean() <= 1e-3        # (a rounding-level change of z can flip an argmax at a near tie)
     for a, b in zip(e1, e2):
         assert np.array_equal(a, b)                    # persistent vs persistent (sc1-only exchange): bit for bit
     import torch
