@@ -145,7 +145,7 @@ struct FastSrc {
 // stage (all converts, then all residuals, ...) with scheduling barriers between the stages: written piece by
 // piece the compiler reuses ten registers and every instruction waits for its predecessor (measured: the
 // dependent chain cost ~14 cycles per instruction under the other waves' MFMA traffic, 3x the whole MFMA phase).
-template <bool XC, int ABL = 0>
+template <bool XC, int ABL = 0, int NP = 3>     // NP = 1: the bf16-operand mode (compute_dtype 1) keeps the hi plane only -- RNE to bf16, one product
 __device__ __forceinline__ void s_split_store(unsigned short* __restrict__ s, const float4 (&r)[4], int tid)
 {
     float v[4][4];          // v[j][i]: piece j, i-th of its four consecutive k
@@ -171,7 +171,11 @@ __device__ __forceinline__ void s_split_store(unsigned short* __restrict__ s, co
     uint2 ph[4], pm[4], pl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ph[j].x = cvt_pk(v[j][0], v[j][1]); ph[j].y = cvt_pk(v[j][2], v[j][3]); }
-    {
+    if constexpr (NP == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(s + off[j]) = ph[j];
+        return;
+    } else {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -201,12 +205,12 @@ __device__ __forceinline__ void s_split_store(unsigned short* __restrict__ s, co
     }
 }
 
-template <bool A_MC, bool B_NC, int ABL = 0, bool FAST = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
+template <bool A_MC, bool B_NC, int ABL = 0, bool FAST = false, int NP = 3>
+__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void gemm_f32s_kernel(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short smem[6 * SPLANE];      // 48 KB: A hi|mid|lo, B hi|mid|lo
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NP * SPLANE];      // 48 KB: A hi|mid|lo, B hi|mid|lo (NP = 1: 16 KB)
     unsigned short* As = smem;
-    unsigned short* Bs = smem + 3 * SPLANE;
+    unsigned short* Bs = smem + NP * SPLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
@@ -274,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
     for (int k0 = kb; k0 < ke; k0 += SBK) {
         if (ABL & 16) { __builtin_amdgcn_s_waitcnt(0x0F70 & 0xC07F); }      // vmcnt(0) only (gfx9 encoding: vmcnt lo [3:0], hi [15:14])
         AVAE_STAMP(0);
-        s_split_store<A_MC, ABL>(As, ra, tid);
-        s_split_store<B_NC, ABL>(Bs, rb, tid);
+        s_split_store<A_MC, ABL, NP>(As, ra, tid);
+        s_split_store<B_NC, ABL, NP>(Bs, rb, tid);
         AVAE_STAMP(1);
         __syncthreads();
         AVAE_STAMP(2);
@@ -291,11 +295,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
         AVAE_STAMP(3);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2][3], b[2][3];
+            bf16x8 a[2][NP], b[2][NP];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     a[t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + offa[s] + p * SPLANE + 32 * t * SLD));
                     b[t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + offb[s] + p * SPLANE + 32 * t * SLD));
                 }
@@ -304,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(GemmArgs g)
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
-            AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) AVAE_PROD(0, 0)
+            if constexpr (NP == 3) { AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) }
+            AVAE_PROD(0, 0)
 #undef AVAE_PROD
         }
         __syncthreads();
@@ -378,7 +383,7 @@ struct TileIter {
     __device__ __forceinline__ void next() { vb += step; seek(); }
 };
 
-template <bool A_MC, bool B_NC>
+template <bool A_MC, bool B_NC, int NP = 3>
 __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];      // 2 stages x (A hi|mid|lo, B hi|mid|lo)
@@ -420,20 +425,20 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nb
                 if (++kt == nk) { kt = 0; ti.next(); }
             };
             issue();
-            s_split_store<XC>(base, r, ptid);
+            s_split_store<XC, 0, NP>(base, r, ptid);
             bool nxt = ti.ok;
             if (nxt) issue();
             __syncthreads();
             for (int G = 0; ; ++G) {                      // consumers work on K tile G of this workgroup's sequence
                 if (!nxt) { __syncthreads(); break; }
-                s_split_store<XC>(base + ((G + 1) & 1) * 6 * SPLANE, r, ptid);
+                s_split_store<XC, 0, NP>(base + ((G + 1) & 1) * 2 * NP * SPLANE, r, ptid);
                 nxt = ti.ok;
                 if (nxt) issue();
                 __syncthreads();
             }
         };
         if (!isb) { FastSrc<A_MC> fs; run(fs, std::integral_constant<bool, A_MC>{}, g.A, g.lda, true, dsm); }
-        else      { FastSrc<B_NC> fs; run(fs, std::integral_constant<bool, B_NC>{}, g.B, g.ldb, false, dsm + 3 * SPLANE); }
+        else      { FastSrc<B_NC> fs; run(fs, std::integral_constant<bool, B_NC>{}, g.B, g.ldb, false, dsm + NP * SPLANE); }
         return;
     }
 
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nb
     const int wm = wave >> 1, wn = wave & 1;
     int offa[2], offb[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { offa[s] = sw_off(64 * wm + l31, 2 * s + h); offb[s] = 3 * SPLANE + sw_off(64 * wn + l31, 2 * s + h); }
+    for (int s = 0; s < 2; ++s) { offa[s] = sw_off(64 * wm + l31, 2 * s + h); offb[s] = NP * SPLANE + sw_off(64 * wn + l31, 2 * s + h); }
     const bool atomic = g.split_k > 1;
     const bool add_bias = g.bias != nullptr && (!atomic || blockIdx.z == 0);
     __syncthreads();
@@ -455,14 +460,14 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nb
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int it = 0; it < nk; ++it, ++G) {
-            const unsigned short* st = dsm + (G & 1) * 6 * SPLANE;
-            bf16x8 a[2][2][3], b[2][2][3];          // [step][tile][plane]
+            const unsigned short* st = dsm + (G & 1) * 2 * NP * SPLANE;
+            bf16x8 a[2][2][NP], b[2][2][NP];          // [step][tile][plane]
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NP; ++p) {
                         a[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offa[s] + p * SPLANE + 32 * t * SLD));
                         b[s][t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + offb[s] + p * SPLANE + 32 * t * SLD));
                     }
@@ -472,7 +477,8 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nb
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][pa], b[s][j][pb], acc[i][j], 0, 0, 0);
-                AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) AVAE_PROD(0, 0)
+                if constexpr (NP == 3) { AVAE_PROD(2, 0) AVAE_PROD(0, 2) AVAE_PROD(1, 1) AVAE_PROD(1, 0) AVAE_PROD(0, 1) }
+                AVAE_PROD(0, 0)
 #undef AVAE_PROD
             }
             __syncthreads();
@@ -500,14 +506,14 @@ __global__ __launch_bounds__(768, 1) void gemm_f32s_ws_kernel(GemmArgs g, int nb
     }
 }
 
-template <bool A_MC, bool B_NC>
+template <bool A_MC, bool B_NC, int NP>
 static hipError_t launch_ws(hipStream_t st, dim3 grid, const GemmArgs& g)
 {
-    constexpr int lds_bytes = 2 * 6 * SPLANE * 2;
+    constexpr int lds_bytes = 2 * 2 * NP * SPLANE * 2;
     static bool attr_set = false;
     static int ncu = 256;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32s_ws_kernel<A_MC, B_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32s_ws_kernel<A_MC, B_NC, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
@@ -516,11 +522,12 @@ static hipError_t launch_ws(hipStream_t st, dim3 grid, const GemmArgs& g)
     const int tiles = (int)grid.x;
     // one workgroup per CU walks its tiles; with split-K every (tile, slice) keeps its own workgroup
     if (grid.z == 1 && tiles > ncu) grid.x = ncu / 8 * 8;
-    hipLaunchKernelGGL((gemm_f32s_ws_kernel<A_MC, B_NC>), grid, dim3(768), lds_bytes, st, g, tiles);
+    hipLaunchKernelGGL((gemm_f32s_ws_kernel<A_MC, B_NC, NP>), grid, dim3(768), lds_bytes, st, g, tiles);
     return hipGetLastError();
 }
 
-hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
+template <int NP>
+static hipError_t gemm_split(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
 {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if ((g.lda | g.ldb) & 3) return hipErrorInvalidValue;
@@ -533,38 +540,47 @@ hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     dim3 grid(tiles, 1, g.split_k > 1 ? g.split_k : 1);
     const GemmArgs& gp = g;
     static const int abl = getenv("AVAE_F32S_ABLATE") ? atoi(getenv("AVAE_F32S_ABLATE")) : 0;     // diagnostics only
+    if constexpr (NP == 3) {
     if (abl && !a_mc && !b_nc) {         // 16 / 17: phase stamps of the predicated / fast-staging main loop (scripts/gemm_stamps.py)
         if (abl == 16)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16>), grid, dim3(256), 0, st, gp);
         else if (abl == 17) hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 16, true>), grid, dim3(256), 0, st, gp);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
+    }
     // fast staging path: no element of any tile needs a predicate the buffer bounds cannot express
     //   k-contiguous operand: K a multiple of the K tile and known on the host;  [k][x] operand: x extent a multiple of 128
     const bool fast = (a_mc ? (g.M % 128 == 0) : (g.K % SBK == 0 && g.dyn_kind != 2)) &&
                       (b_nc ? (g.N % 128 == 0) : (g.K % SBK == 0 && g.dyn_kind != 2)) && abl != 99;
     static const int ws = getenv("AVAE_F32S_WS") ? atoi(getenv("AVAE_F32S_WS")) : 1;      // 0: phase-structured kernel (A/B experiments)
+    static const int ws1 = getenv("AVAE_BF16D_WS") ? atoi(getenv("AVAE_BF16D_WS")) : 0;   // the one-plane form: wave-specialised kernel off by default
     // one 768-thread workgroup per CU pays ~9 us per tile that nothing overlaps (first loads, C stores, dispatch):
     // it wins where a workgroup's K extent is long (measured cross-over between K = 1024 and 1536)
     const int k_per_wg = g.split_k > 1 ? (g.K + g.split_k - 1) / g.split_k : g.K;
-    if (fast && (ws == 2 || (ws == 1 && k_per_wg >= 1536))) {
-        if (!a_mc && !b_nc)      return launch_ws<false, false>(st, grid, gp);
-        else if (!a_mc && b_nc)  return launch_ws<false, true>(st, grid, gp);
-        else if (a_mc && b_nc)   return launch_ws<true, true>(st, grid, gp);
-        else                     return launch_ws<true, false>(st, grid, gp);
+    const int wsel = NP == 3 ? ws : ws1;
+    if (fast && (wsel == 2 || (wsel == 1 && k_per_wg >= 1536))) {
+        if (!a_mc && !b_nc)      return launch_ws<false, false, NP>(st, grid, gp);
+        else if (!a_mc && b_nc)  return launch_ws<false, true, NP>(st, grid, gp);
+        else if (a_mc && b_nc)   return launch_ws<true, true, NP>(st, grid, gp);
+        else                     return launch_ws<true, false, NP>(st, grid, gp);
     }
     if (fast) {
-        if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 0, true>), grid, dim3(256), 0, st, gp);
-        else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true, 0, true>), grid, dim3(256), 0, st, gp);
-        else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true, 0, true>), grid, dim3(256), 0, st, gp);
-        else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false, 0, true>), grid, dim3(256), 0, st, gp);
+        if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 0, true, NP>), grid, dim3(256), 0, st, gp);
+        else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true, 0, true, NP>), grid, dim3(256), 0, st, gp);
+        else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true, 0, true, NP>), grid, dim3(256), 0, st, gp);
+        else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false, 0, true, NP>), grid, dim3(256), 0, st, gp);
         return hipGetLastError();
     }
-    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false>), grid, dim3(256), 0, st, gp);
-    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true>), grid, dim3(256), 0, st, gp);
-    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true>), grid, dim3(256), 0, st, gp);
-    else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false>), grid, dim3(256), 0, st, gp);
+    if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32s_kernel<false, false, 0, false, NP>), grid, dim3(256), 0, st, gp);
+    else if (!a_mc && b_nc)  hipLaunchKernelGGL((gemm_f32s_kernel<false, true, 0, false, NP>), grid, dim3(256), 0, st, gp);
+    else if (a_mc && b_nc)   hipLaunchKernelGGL((gemm_f32s_kernel<true, true, 0, false, NP>), grid, dim3(256), 0, st, gp);
+    else                     hipLaunchKernelGGL((gemm_f32s_kernel<true, false, 0, false, NP>), grid, dim3(256), 0, st, gp);
     return hipGetLastError();
 }
+
+hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g) { return gemm_split<3>(st, a_mc, b_nc, g); }
+// bf16-operand GEMM straight from fp32 operands in any layout: each element rounded to bf16 (RNE) on its way into LDS, ONE
+// product on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the values of cvt_bf16 + gemm_bf16_nt without the conversion passes
+hipError_t gemm_bf16_direct(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g) { return gemm_split<1>(st, a_mc, b_nc, g); }
 
 }  // namespace avae

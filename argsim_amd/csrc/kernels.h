@@ -33,6 +33,9 @@ hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 // same contract on the bf16 matrix cores: every fp32 operand element is split into three bf16 in registers and
 // six partial products are accumulated in fp32 (gemm_f32s.hip; fp32-accurate, 128x128 tiles only: g.thin ignored)
 hipError_t gemm_f32s(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
+// bf16-operand GEMM from fp32 operands in any layout (gemm_f32s.hip, one plane): RNE to bf16 while staging into LDS, one
+// product, fp32 accumulate; no conversion pass (g.thin ignored)
+hipError_t gemm_bf16_direct(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 
 // ---------------------------------------------------------------- bf16-operand GEMM (gemm_bf16.hip)
 // fp32 -> bf16 panel: transpose == false: src [rows][cols] (ld) -> dst [rows][ldd];  transpose == true:

@@ -49,8 +49,11 @@ struct avae_ctx {
     int persistent = 1;
     bool first_step_checked = false;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
+    int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
+    //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
@@ -261,6 +264,11 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
     GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin,
                pair ? pair->A : nullptr, pair ? pair->B : nullptr, pair ? pair->C : nullptr, pair ? pair->bias : nullptr};
     Timed t(h, 0, 2.0 * M * N * K * (pair ? 2 : 1), dyn, dyn_kind == 1 ? M : (dyn_kind == 2 ? K : 0));
+    if (h->cfg.compute_dtype == 1 && h->bf16_direct) {
+        // bf16 operands rounded on the way into LDS, straight from the fp32 operands in whatever layout: no conversion passes
+        AV_CHECK(gemm_bf16_direct(h->stream, a_mc, b_nc, g));
+        return 0;
+    }
     if (h->cfg.compute_dtype == 1) {
         // bf16 operands: convert (transposing [k][x] operands) into k-contiguous panels, then one NT kernel
         const int Kp = (K + 7) & ~7;
@@ -323,6 +331,11 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
         if (M <= 512)
             return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 1);
     }
+    // A GEMM whose row count is only known on the device (the ids present in the batch: about V / 2 of the static bound
+    // of V rows) with a narrow output: 128x128 tiles over the rows that exist are fewer than one round of the chip (dE of
+    // the table-fed layers: 112 tiles for 768 slots, 49 TFLOP/s).  64x64 tiles: four times the tiles, deterministic.
+    if (h->dyn_thin && dyn_kind == 1 && h->cfg.compute_dtype == 0 && nt <= 4 && tiles <= 512 && K >= 1024)
+        return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 2);
     if (tiles > 256 && tiles % 256 != 0) {
         int main_mt = mt;
         while (main_mt > 0 && (main_mt * nt) % 256 != 0) --main_mt;
@@ -955,8 +968,10 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_stagger")) { h->gru_stagger = value; return 0; }
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
+    if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
     if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
+    if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");

@@ -295,6 +295,22 @@ def main():
 
                 out["table_l1_0"] = leg({'table_l1': 0}, "same workload with a per-token input projection in the first encoder / decoder layer (option table_l1 = 0)")
                 out["enc_top1_0"] = leg({'enc_top1': 0}, "same workload with all %d steps of the top encoder layer's backward direction (option enc_top1 = 0)" % S)
+                # SURVEY 8(d)'s second synthetic set: RAGGED rows (len = clip(round(LogNormal(ln 24, 0.5)), 2, S), eos padded)
+                ids_r = synth.batch(B, S, CFG['dim_tgt'], ragged=True, seed=0)
+                tok_r = int((ids_r != 1).sum()) + B                      # decoder positions incl. the eos step, model.py:91-95
+                ids_rd = torch.as_tensor(ids_r).to(model.device)
+                for i in range(3):
+                    model.train_step(ids_rd, ids_rd, seed=i)
+                fence()
+                t1 = time.perf_counter()
+                for i in range(A.steps):
+                    model.train_step(ids_rd, ids_rd, seed=50 + i)
+                fence()
+                dtr = (time.perf_counter() - t1) / A.steps
+                out["ragged"] = {"value": B / dtr, "unit": "sentences/sec", "tokens_per_sec": tok_r / dtr, "ms_per_step": 1e3 * dtr,
+                                 "mean_len": float((ids_r != 1).sum(1).mean()), "max_len": int((ids_r != 1).sum(1).max()),
+                                 "padded_step_share": 1.0 - float((ids_r != 1).sum()) / float(B * int((ids_r != 1).sum(1).max())),
+                                 "what": "same model, RAGGED synthetic batch %d x %d (LogNormal lengths); not the headline" % (B, S)}
                 out["graph_as_written"] = leg({'table_l1': 0, 'enc_top1': 0}, "both off: every FLOP of the reference's graph executed (2 153 GFLOP per step)")
             if not A.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
