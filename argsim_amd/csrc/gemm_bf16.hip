@@ -414,6 +414,161 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt256_kernel(GemmBf16Args g)
     }
 }
 
+// ---------------------------------------------------------------- the TN form: both operands stored [k][x]
+// C[M,N] = alpha * A^T B with A [K][lda] (m contiguous) and B [K][ldb] (n contiguous), bf16: the weight-gradient GEMMs
+// dW = dgi^T x, dR = dgh^T h_prev, dE = dlogits^T ho, whose operands are activations stored row-major by their producers
+// ([row = k][column = m or n]).  The k-contiguous form above needed both operands transposed first (cvt_transpose /
+// transpose_bf16 passes over 1.6 GB arrays at configs[2]); here a K tile goes to LDS as it lies in memory ([64 k][256 x],
+// rows padded to 288 bf16 = 144 dwords = 16 mod 64 banks) and the MFMA fragments are read with ds_read_b64_tr_b16, the
+// CDNA4 transposing LDS read: per 16-lane group a 4 (k) x 16 (x) block, lane 4q + p supplying the address of (row q,
+// columns 4p..4p+3), lane i receiving column i's four k (cdna_hip_programming.md T10).  Two reads give a lane its eight
+// consecutive k of v_mfma_f32_32x32x16_bf16's operand map (lane (r, h): row r, k = 8h..8h+7).  With the 16-dword row
+// skew the two groups of a 32-lane half touch 8 disjoint sets of 8 banks: conflict free.  Same 256x256x64 tile, 8 waves,
+// double-buffered LDS and epilogue as gemm_bf16_nt256_kernel.  M, N, lda, ldb multiples of 8.
+constexpr int LDT = T2 + 32;
+constexpr int kTnLds = 2 * 2 * BKH * LDT * 2;        // bytes: [buffer][A | B][64 k][LDT] bf16 = 144 KB
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void load_panel_kx(uint4 (&r)[4], const unsigned short* __restrict__ P, int ld, int x0, int X, int k0, int K, int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const int f = tid + 512 * rep, k = k0 + (f >> 5), x = x0 + ((f & 31) << 3);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (k < K && x < X) v = *reinterpret_cast<const uint4*>(P + (size_t)k * ld + x);
+        r[rep] = v;
+    }
+}
+__device__ __forceinline__ void store_panel_kx(unsigned short* __restrict__ s, const uint4 (&r)[4], int tid)
+{
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const int f = tid + 512 * rep;
+        *reinterpret_cast<uint4*>(s + (f >> 5) * LDT + ((f & 31) << 3)) = r[rep];
+    }
+}
+// the fragment of the 32 x-columns starting at xb for the 16 k starting at ks: `toff` = this lane's offset inside the block pair
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* img, int off)
+{
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + off + 4 * LDT));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_tn256_kernel(GemmBf16Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int K = g.K;
+    const int M = g.M;
+    if (g.dyn_kind == 2) K = min(K, *g.dyn);
+    const int tiles_n = (g.N + T2 - 1) / T2;
+    const int bid = blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * T2, n0 = tn * T2;
+    int kb = 0, ke = K;
+    if (g.split_k > 1) {
+        const int ktiles = (K + BKH - 1) / BKH, per = (ktiles + g.split_k - 1) / g.split_k;
+        kb = blockIdx.z * per * BKH; ke = min(K, kb + per * BKH);
+        if (kb >= ke) return;                       // (uniform over the workgroup: EXEC stays full for the transposing reads)
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this lane's place in the 4 x 16 blocks of a transposing read: group gq = lane / 16 -> k half (gq >> 1) and x half (gq & 1)
+    const int gq = lane >> 4, li = lane & 15;
+    const int toff = (8 * (gq >> 1) + (li >> 2)) * LDT + 16 * (gq & 1) + 4 * (li & 3);
+
+    uint4 ra[4], rb[4];
+    load_panel_kx(ra, g.A, g.lda, m0, M, kb, ke, tid);
+    load_panel_kx(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
+    store_panel_kx(smem3, ra, tid);
+    store_panel_kx(smem3 + BKH * LDT, rb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += BKH, cur ^= 1) {
+        const bool more = k0 + BKH < ke;
+        if (more) {
+            load_panel_kx(ra, g.A, g.lda, m0, M, k0 + BKH, ke, tid);
+            load_panel_kx(rb, g.B, g.ldb, n0, g.N, k0 + BKH, ke, tid);
+        }
+        const unsigned short* As = smem3 + cur * (2 * BKH * LDT);
+        const unsigned short* Bs = As + BKH * LDT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = tr_frag(As, toff + 16 * s * LDT + 128 * wm + 32 * t);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t] = tr_frag(Bs, toff + 16 * s * LDT + 64 * wn + 32 * t);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            unsigned short* An = smem3 + (cur ^ 1) * (2 * BKH * LDT);
+            store_panel_kx(An, ra, tid);
+            store_panel_kx(An + BKH * LDT, rb, tid);
+        }
+        __syncthreads();
+    }
+    const bool atomic = g.split_k > 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 64 * wn + 32 * j + l31;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 128 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                const float v = g.alpha * acc[i][j][r];
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+// C (M x N) = alpha * A^T B (+ C): A [K][lda], B [K][ldb] bf16 row-major as their producers wrote them.  K split over
+// ~2 rounds of one workgroup per CU with float atomics INTO C (which must hold the value to add onto: the zero-filled
+// gradient) when g.split_k > 1, as gemm_bf16_nt re-derives it; g.dyn / dyn_kind 2: device-side K.
+hipError_t gemm_bf16_tn(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g)
+{
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if ((lda | ldb | g.M | g.N) & 7 || g.dyn_kind == 1 || g.bias) return hipErrorInvalidValue;
+    GemmBf16Args a{A, B, g.C, nullptr, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, g.accumulate, g.split_k, g.dyn, g.dyn_kind};
+    const int big_tiles = ((g.M + T2 - 1) / T2) * ((g.N + T2 - 1) / T2);
+    int s2 = g.split_k > 1 ? (512 + big_tiles / 2) / big_tiles : 1;
+    s2 = std::max(1, std::min(std::min(s2, 16), std::max(1, g.K / (4 * BKH))));
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTnLds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    a.split_k = s2;
+    if (g.split_k > 1 && s2 == 1) a.accumulate = 1;       // the caller's slices were going to ADD into C
+    dim3 grid(big_tiles, 1, s2);
+    hipLaunchKernelGGL(gemm_bf16_tn256_kernel, grid, dim3(512), kTnLds, st, a);
+    return hipGetLastError();
+}
+
 // operands already converted: A [M][lda] bf16, B [N][ldb] bf16, lda/ldb multiples of 8
 hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g)
 {

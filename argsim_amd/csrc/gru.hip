@@ -1460,6 +1460,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const float* __restrict__ p_do = J.dh_out;
     float* __restrict__ p_dgi = J.dgi;
     float* __restrict__ p_dghw = J.dgh;
+    unsigned short* __restrict__ p_dgi16 = BF ? J.dgi16 : nullptr;      // BF: the gate gradients as bf16 row-major INSTEAD of fp32
+    unsigned short* __restrict__ p_dgh16 = BF ? J.dgh16 : nullptr;      // (the bf16 GEMMs' operands as they stand: no conversion pass)
     float* p_dh0 = J.dh0;
     float* p_carry = J.carry;
     const int* p_lens = a.lens;
@@ -1479,6 +1481,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(xg);
     const __amdgpu_buffer_rsrc_t rs_sv = make_rsrc(p_sv), rs_hp = make_rsrc(p_hp), rs_do = make_rsrc(p_do ? p_do : p_hp);
     const __amdgpu_buffer_rsrc_t rs_dgi = make_rsrc(p_dgi), rs_dghw = make_rsrc(p_dghw);
+    const __amdgpu_buffer_rsrc_t rs_dgi16 = make_rsrc(reinterpret_cast<const float*>(p_dgi16 ? p_dgi16 : reinterpret_cast<unsigned short*>(p_dgi)));
+    const __amdgpu_buffer_rsrc_t rs_dgh16 = make_rsrc(reinterpret_cast<const float*>(p_dgh16 ? p_dgh16 : reinterpret_cast<unsigned short*>(p_dghw)));
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {      // byte offset of this lane's first piece of dgh_{p+1}
         if constexpr (BF) return xch_lane_offset(pos_map(p + 1, len_a, j_rev), row0, wk * (WKB / 8), n, kh, B, 3 * D / 2);
         return xch_lane_offset(pos_map(p + 1, len_a, j_rev), row0, wk * (WKB / 4), n, kh, B, 3 * D);
@@ -1682,10 +1686,28 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 else { bstore1_sc1(x0, rs_dgh, o0); bstore1_sc1(x1, rs_dgh, o0 + 1024u); bstore1_sc1(x2, rs_dgh, o0 + 2048u); }
             }
             const unsigned orow = (rix * (unsigned)ldg + ht * 48 + gn_l * 3) * 4u;
+            if (BF && p_dgi16 != nullptr) {
+                // 16-bit row-major copies: the even unit's lane takes its odd neighbour's three values (quad-permute DPP: lanes
+                // 0,2 read lanes 1,3) and stores the six bf16 of both units as one 12-byte access
+                const float dnr = dn * r_;
+                const float o_r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dr), 0xF5, 0xF, 0xF, false));
+                const float o_u = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(du), 0xF5, 0xF, 0xF, false));
+                const float o_n = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dn), 0xF5, 0xF, 0xF, false));
+                const float o_nr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dnr), 0xF5, 0xF, 0xF, false));
+                if ((gn_l & 1) == 0) {
+                    const u32x3 vh = {pack_bf16(dr, du), pack_bf16(dnr, o_r), pack_bf16(o_u, o_nr)};
+                    const u32x3 vi = {pack_bf16(dr, du), pack_bf16(dn, o_r), pack_bf16(o_u, o_n)};
+                    __builtin_amdgcn_raw_buffer_store_b96(vh, rs_dgh16, (int)(orow >> 1), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow >> 1), 0, 0);
+                }
+                if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
+                else carry_reg = dH * u;
+            } else {
             bstore3(dr, du, dn * r_, rs_dghw, orow);                 // the row-major copy the weight-gradient GEMM reads
             if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
             else carry_reg = dH * u;
             bstore3(dr, du, dn, rs_dgi, orow);
+            }
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
         len_a = len2; len_g = len2g;
@@ -2017,8 +2039,17 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     return hipSuccess;
 }
 
+bool gru_backward_uses_team(const GruArgs& a, bool persistent)
+{
+    int T = 0, C = 0;
+    return persistent && team_geometry(a, false, &T, &C) && !a.ablate && a.item_pipeline == 2;
+}
+
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
 {
+    for (int i = 0; i < a.njobs; ++i)      // 16-bit gate gradients are written by the bf16 team kernels only
+        if ((a.job[i].dgi16 || a.job[i].dgh16) && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
+
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     if (persistent) {
         int T = 0, C = 0;

@@ -44,6 +44,9 @@ hipError_t cvt_bf16(hipStream_t st, const float* src, int ld, bool transpose, in
                     unsigned short* dst, int ldd);
 // C = alpha * A B^T (+bias)(+C): A [M][lda], B [N][ldb] bf16 k-contiguous; the other fields as in GemmArgs
 hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);
+// C = alpha * A^T B (+C): A [K][lda] (m contiguous), B [K][ldb] (n contiguous) bf16, read with transposing LDS loads -- no
+// transposed copy of either operand (M, N, lda, ldb multiples of 8; split_k > 1: float atomics into C)
+hipError_t gemm_bf16_tn(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);
 // bf16 [K][X] (row stride ld) -> bf16 [X][ldk] (ldk = K rounded up to 8, pad zero-filled)
 hipError_t transpose_bf16(hipStream_t st, const unsigned short* src, int ld, int K, int X, unsigned short* dst, int ldk);
 
@@ -68,6 +71,8 @@ struct GruJob {
     const float* dh_out;  // grad wrt hs (same indexing as hs: ldh) or nullptr
     float* dgi;           // (S,B,ldg) G16 columns (+ job offset)
     float* dgh;           // (S,B,ldg)
+    unsigned short* dgi16; // optional, bf16 team kernels only: dgi / dgh as bf16 (S,B,ldg) row-major INSTEAD of the fp32 arrays
+    unsigned short* dgh16; //   (gru_backward_uses_team tells whether the launch will honour them)
     float* dh0;           // (B,D) or nullptr
     float* carry;         // (B,D) scratch: dH_{p+1} * u_{p+1}
     float* dbW;           // (3D) G16 += column sums of dgi (or nullptr)
@@ -94,6 +99,7 @@ struct GruArgs {
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
 bool gru_forward_uses_team(const GruArgs& a, bool persistent);      // true: the launch runs the LDS-weight team kernels (gi_rows honoured)
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
+bool gru_backward_uses_team(const GruArgs& a, bool persistent);     // true: the launch runs the LDS-weight team kernels (dgi16 / dgh16 honoured in bf16 mode)
 bool gru_dim_supported(int D);
 // one GRU step from a zero state for B rows (the top encoder layer's backward direction: gru.hip "one step from a zero
 // state"): gi (B, 3D) / bR G16; h -> h_out[b * ldo + j]; sv (B, D, 4) = r, u, n, hn or nullptr

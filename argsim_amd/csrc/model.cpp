@@ -52,6 +52,7 @@ struct avae_ctx {
     int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
+    int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
@@ -132,6 +133,7 @@ struct Ws {
     // backward
     float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
+    unsigned short *dgi16_d, *dgh16_d, *dgi16_e, *dgh16_e;      // bf16 mode: the gate gradients as the BPTT team kernels write them (bf16_tn)
     int32_t* scat;                        // embed_scatter_add2's token lists
     int32_t *grp_src, *grp_tgt;           // id_groups_build scratch of the two id sources (use_table)
     int32_t *tokrow_src, *tokrow_tgt;
@@ -212,6 +214,9 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.dhs[0] = b.take<float>(rs * 2 * D); w.dhs[1] = b.take<float>(rs * 2 * D);
         w.dgi_e = b.take<float>(rs * 6 * D); w.dgh_e = b.take<float>(rs * 6 * D);
         w.demb_src = b.take<float>(rs * D); w.demb_tgt = b.take<float>(rt * D);
+        const bool g16 = h->cfg.compute_dtype == 1;
+        w.dgi16_d = b.take<unsigned short>(g16 ? rt * 3 * D : 0); w.dgh16_d = b.take<unsigned short>(g16 ? rt * 3 * D : 0);
+        w.dgi16_e = b.take<unsigned short>(g16 ? rs * 6 * D : 0); w.dgh16_e = b.take<unsigned short>(g16 ? rs * 6 * D : 0);
         w.scat = b.take<int32_t>(embed_scatter_scratch_ints(rs + rt, V));
         w.dew = b.take<float>(tab_s ? (size_t)V * 6 * D : (tab_t ? (size_t)V * 3 * D : 0));  // gate gradients of a table-fed layer summed by id
     }
@@ -305,6 +310,34 @@ int gemm_bf16_pre(avae_ctx* h, const unsigned short* A16, int lda16, bool a_mc, 
     AV_CHECK(gemm_bf16_nt(h->stream, Ap, lda_p, h->bfB, Kp, g));
     return 0;
 }
+
+int grad_split(int M, int N, int K);
+// bf16 mode, weight gradient C (M x N) += alpha * A^T B over K rows with BOTH operands row-major [k][x]: bf16 as a producer
+// wrote them (A16 / B16) or fp32 converted row by row (no transpose); the GEMM reads them through transposing LDS loads
+// (gemm_bf16_tn).  C holds the zero-filled gradient; dynk: device-side K.
+int gemm_tn16(avae_ctx* h, const unsigned short* A16, const float* A32, int lda, const unsigned short* B16, const float* B32, int ldb,
+              float* C, int ldc, int M, int N, int K, float alpha, const int* dynk)
+{
+    const int s = grad_split(M, N, K);
+    GemmArgs g{nullptr, nullptr, C, nullptr, M, N, K, lda, ldb, ldc, alpha, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, 0, nullptr, nullptr, nullptr, nullptr};
+    Timed t(h, 0, 2.0 * M * N * K, dynk, dynk ? K : 0);
+    int la = lda, lb = ldb;
+    if (!A16) {
+        la = (M + 7) & ~7;
+        AV_TRY(grow_bf16(h, &h->bfA, &h->bfA_cap, (size_t)K * la));
+        AV_CHECK(cvt_bf16(h->stream, A32, lda, false, K, M, h->bfA, la));
+        A16 = h->bfA;
+    }
+    if (!B16) {
+        lb = (N + 7) & ~7;
+        AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)K * lb));
+        AV_CHECK(cvt_bf16(h->stream, B32, ldb, false, K, N, h->bfB, lb));
+        B16 = h->bfB;
+    }
+    AV_CHECK(gemm_bf16_tn(h->stream, A16, la, B16, lb, g));
+    return 0;
+}
+static bool tn16_ok(const avae_ctx* h, int M, int N) { return h->cfg.compute_dtype == 1 && h->bf16_tn && ((M | N) & 7) == 0 && (size_t)M * N >= (size_t)1 << 19; }
 
 // C = alpha * op(A) op(B) (+bias) with launch shaping for the 256-CU chip (k-contiguous A only):
 //  * thin outputs (M <= 512): 32x128 block tiles so that the few rows still spread over many CUs;
@@ -603,8 +636,11 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         // second transposes the 2-byte source once -- no fp32 gradient is written or converted (10.7 GB less traffic per
         // step at configs[2]); same values as rounding the fp32 gradient, so the results do not change
         AV_TRY(gemm_bf16_pre(h, h->bfP, V, false, P + h->oE, D, true, w.dho, D, rt, D, V, isd, 0, 1, w.ntok, 1));
+        if (tn16_ok(h, V, D)) AV_TRY(gemm_tn16(h, h->bfP, nullptr, V, nullptr, w.ho, D, G + h->oE, D, V, D, rt, isd, w.ntok));      // (no transposed copy of the 2-byte gradient)
+        else {
         const int s = grad_split(V, D, rt);
         AV_TRY(gemm_bf16_pre(h, h->bfP, V, true, w.ho, D, true, G + h->oE, D, V, D, rt, isd, s > 1 ? 0 : 1, s, w.ntok, 2));
+        }
     } else {
     AV_TRY(gemm(h, false, true, w.logits, V, P + h->oE, D, w.dho, D, rt, D, V, isd, nullptr, 0, 0, w.ntok, 1, true));
     // (V x D output over K = N rows: 256 tiles of 128x128 x 3 K slices, float atomics into the zero-filled G; the gather
@@ -631,6 +667,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
         j.dh0 = w.dh0 + (size_t)i * B * D; j.carry = w.carry;
         j.dbW = G + p.bW; j.dbR = G + p.bR;
+        // bf16 mode: the team kernels write the gate gradients as bf16, the operand of the three GEMMs below as it stands
+        // (a table-fed layer keeps fp32: its gradients are summed by id first)
+        const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt)) && gru_backward_uses_team(a, h->persistent != 0);
+        if (g16) { j.dgi16 = w.dgi16_d; j.dgh16 = w.dgh16_d; }
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -643,6 +683,12 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
             AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, w.demb_tgt, D, U, D, 3 * D, 1.f, nullptr, 0, 0, cnt, 1));
             AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
+        } else if (g16) {
+            const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
+            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, nullptr, x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, nullptr, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, nullptr));
+            float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
+            AV_TRY(gemm_bf16_pre(h, w.dgi16_d, 3 * D, false, P + p.W, D, true, dx, D, rt, D, 3 * D, 1.f, 0, 1, nullptr, 0));
         } else {
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         {   // dW = dgi^T x and dR = dgh^T h_prev: same shape over the same rows, one launch
@@ -700,6 +746,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             j.dh0 = nullptr; j.carry = w.carry + (size_t)d * B * D;
             j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
+        const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs)) && gru_backward_uses_team(a, h->persistent != 0);
+        if (g16) for (int d = 0; d < a.njobs; ++d) { a.job[d].dgi16 = w.dgi16_e + d * 3 * D; a.job[d].dgh16 = w.dgh16_e + d * 3 * D; }
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -707,6 +755,28 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         const bool table = i == 0 && use_table(h, rs);
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
         float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
+        if (g16) {
+            // bf16 mode, gate gradients written as bf16 by the BPTT kernels: every GEMM of the layer reads them as they stand
+            const int Gc = a.njobs * 3 * D;                          // gate columns of the directions that ran
+            if (i == 0) {     // first layer (per-token form): input gradient, scatter, embedding bucket -- the fixed order of announcements
+                AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, nullptr, 0));
+                AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
+                fire_hook(h, 2 + 2 * L);
+                hook_flush(h);
+            }
+            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, nullptr, x, In, G + p.W, In, Gc, In, rs, 1.f, nullptr));
+            if (top1) AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));
+            for (int d = 0; d < a.njobs; ++d)
+                AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, nullptr));
+            if (i > 0) AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, nullptr, 0));
+            if (top1) {
+                AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
+                AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In));
+            }
+            cur ^= 1;
+            fire_hook(h, 2 + L + (L - 1 - i));
+            continue;
+        }
         if (i == 0) {
             // First encoder layer: its input gradient completes the embedding gradient.  That bucket is ALWAYS announced here,
             // before this layer's two weight-gradient GEMMs (its all-reduce runs beside them), and this layer's own bucket
@@ -969,6 +1039,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
+    if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
     if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
     if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
     if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }
@@ -1064,6 +1135,13 @@ int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const flo
     if (!h) return 1;
     // split_k == -1 selects the thin (32x128 tile) variant, 1000 + s the 64x64-tile variant with s K slices
     return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : (split_k >= 1000 ? split_k - 1000 : split_k), nullptr, 0, split_k < 0 ? 1 : (split_k >= 1000 ? 2 : 0));
+}
+// test hook: C (M x N) += alpha * A^T B with A (K x M, lda), B (K x N, ldb) fp32 row-major, operands rounded to bf16 row by
+// row and read through the transposing-LDS-load GEMM (gemm_tn16 / gemm_bf16_tn); C must hold the value to add onto
+int avae_debug_gemm_tn16(avae_handle h, const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc, float alpha)
+{
+    if (!h) return 1;
+    return gemm_tn16(h, nullptr, A, lda, nullptr, Bm, ldb, Cm, ldc, M, N, K, alpha, nullptr);
 }
 int avae_bucket_count(avae_handle h) { return h ? (int)h->buckets.size() : 0; }
 int avae_bucket_info(avae_handle h, int i, int64_t* offset, int64_t* count)

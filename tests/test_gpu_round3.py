@@ -231,3 +231,27 @@ def test_top_layer_backward_direction_one_step_equals_the_full_form(case):
             continue
         assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b) + 1e-12, k
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ bf16 mode: transposing-LDS-load GEMM
+@pytest.mark.parametrize("M,N,K", [(1536, 512, 4096), (3072, 1024, 1100), (8192, 512, 777), (264, 1032, 130)])
+def test_bf16_tn_gemm_reads_row_major_operands(M, N, K):
+    """gemm_bf16_tn (compute_dtype 1): C += A^T B with both operands row-major [k][x] bf16, fragments read with
+    ds_read_b64_tr_b16 -- against torch on the SAME bf16-rounded operands in float64.  Shapes: a weight gradient with a K
+    split, a K that is no multiple of the 64-deep tile, the vocabulary-sized output, edge tiles in M and N."""
+    import ctypes as C
+    import torch
+    from argsim_amd.model import VAE
+    m = VAE('train', dtype='bf16', dim_tgt=64, dim_emb=16, dim_rep=8, rnn_layers=1)
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn((K, M), device='cuda', generator=g) * 0.5
+    B = torch.randn((K, N), device='cuda', generator=g) * 0.5
+    Cm = torch.full((M, N), 0.25, device='cuda')
+    m._stream()
+    rc = m._l.avae_debug_gemm_tn16(m._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), M, N, K, M, N, N, 0.5)
+    assert rc == 0, m._l.avae_last_error(m._h)
+    torch.cuda.synchronize()
+    ref = 0.25 + 0.5 * (A.bfloat16().double().t() @ B.bfloat16().double())
+    err = float((Cm.double() - ref).abs().max())
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err          # fp32 accumulation over K products of O(1/4)
+    m.close()
