@@ -75,6 +75,7 @@ struct avae_ctx {
     int timing = 0, timing_on = 0;
     // bf16-operand GEMM mode (compute_dtype = 1): converted operand panels
     unsigned short *bfA = nullptr, *bfB = nullptr; size_t bfA_cap = 0, bfB_cap = 0;
+    unsigned short* keep_a16 = nullptr;       // one-shot: the next bf16-mode GEMM converts its (k-contiguous) A operand HERE and leaves it for the backward (gemm_raw)
     unsigned short* bfP = nullptr; size_t bfP_cap = 0;     // bf16 mode: (softmax - onehot)/N as written by softmax_ce_kernel, (N,V) bf16
     // (dyn / dyn_max: a GEMM whose M or K is a device-side count -- its FLOPs are scaled by count / static bound at collection)
     struct Stamp { hipEvent_t a, b; int cls; double flops; const int* dyn; int dyn_max; };
@@ -133,6 +134,10 @@ struct Ws {
     // backward
     float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
+    std::vector<unsigned short*> x16_e, x16_d;                 // bf16 mode: the layer inputs as the forward GEMMs converted them (row-major: the backward's TN operand)
+    const unsigned short* x16_kept_e(int i) const { return x16_valid ? x16_e[i] : nullptr; }
+    const unsigned short* x16_kept_d(int i) const { return x16_valid ? x16_d[i] : nullptr; }
+    bool x16_valid = false;
     unsigned short *dgi16_d, *dgh16_d, *dgi16_e, *dgh16_e;      // bf16 mode: the gate gradients as the BPTT team kernels write them (bf16_tn)
     int32_t* scat;                        // embed_scatter_add2's token lists
     int32_t *grp_src, *grp_tgt;           // id_groups_build scratch of the two id sources (use_table)
@@ -175,6 +180,10 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
     w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
+    w.x16_e.assign(L, nullptr); w.x16_d.assign(L, nullptr);
+    w.x16_valid = train && h->cfg.compute_dtype == 1 && h->bf16_tn && !h->bf16_direct && D % 8 == 0;
+    if (w.x16_valid)
+        for (int i = 1; i < L; ++i) { w.x16_e[i] = b.take<unsigned short>(rs * 2 * D); w.x16_d[i] = b.take<unsigned short>(rt * D); }
     for (int i = 0; i < L; ++i) {
         w.e_gi[i] = b.take<float>(rs * 6 * D);
         w.e_hs[i] = b.take<float>(rs * 2 * D);
@@ -277,11 +286,14 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
     if (h->cfg.compute_dtype == 1) {
         // bf16 operands: convert (transposing [k][x] operands) into k-contiguous panels, then one NT kernel
         const int Kp = (K + 7) & ~7;
-        AV_TRY(grow_bf16(h, &h->bfA, &h->bfA_cap, (size_t)M * Kp));
+        unsigned short* a16 = nullptr;
+        if (h->keep_a16 && !a_mc && Kp == K) { a16 = h->keep_a16; }      // a layer input: its bf16 copy [M][K] stays for the weight-gradient GEMM of the backward
+        h->keep_a16 = nullptr;
+        if (!a16) { AV_TRY(grow_bf16(h, &h->bfA, &h->bfA_cap, (size_t)M * Kp)); a16 = h->bfA; }
         AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)N * Kp));
-        AV_CHECK(cvt_bf16(h->stream, A, lda, a_mc, a_mc ? K : M, a_mc ? M : K, h->bfA, Kp));
+        AV_CHECK(cvt_bf16(h->stream, A, lda, a_mc, a_mc ? K : M, a_mc ? M : K, a16, Kp));
         AV_CHECK(cvt_bf16(h->stream, Bm, ldb, b_nc, b_nc ? K : N, b_nc ? N : K, h->bfB, Kp));
-        AV_CHECK(gemm_bf16_nt(h->stream, h->bfA, Kp, h->bfB, Kp, g));
+        AV_CHECK(gemm_bf16_nt(h->stream, a16, Kp, h->bfB, Kp, g));
         return 0;
     }
     // compute_dtype 2: fp32 operands split into 3 x bf16 on the fly (6 partial products, fp32-accurate); thin
@@ -351,6 +363,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
          const int* dyn = nullptr, int dyn_kind = 0, bool allow_atomic = false)
 {
     const int mt = (M + 127) / 128, nt = (N + 127) / 128, tiles = mt * nt;
+    unsigned short* const keep = h->keep_a16;           // (bf16 mode: where the converted A operand is to stay, see gemm_raw)
     if (split_k != 0 || a_mc || dyn_kind == 2)
         return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, split_k ? split_k : 1, dyn, dyn_kind);
     if (tiles <= 96) {
@@ -379,6 +392,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
             AV_TRY(gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, main_rows, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind));
             // rows beyond the device-side row count hold unread garbage either way: the tail keeps the static bound
             const float* At = A + (size_t)main_rows * lda; float* Ct = C + (size_t)main_rows * ldc;
+            if (keep) h->keep_a16 = keep + (size_t)main_rows * K;
             if (allow_atomic && !accumulate && ldc == N && K >= 1024) {
                 // backward only: a few rows x a long K (dho: 256 rows x K = 8192 took 0.2 ms on 32 thin tiles):
                 // K split over ~768 workgroups of full tiles with float atomics instead
@@ -473,8 +487,11 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             AV_CHECK(id_groups_build(h->stream, w.src_tm, rs, V, w.grp_src, save));
             AV_CHECK(rows_gather(h->stream, w.emb_src, h->P + h->oE, id_groups_uid(w.grp_src, rs, V), cnt, std::min(V, rs), D));
             AV_TRY(gemm(h, false, false, w.emb_src, D, h->P + p.W, D, w.ew, 6 * D, std::min(V, rs), 6 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
-        } else
+        } else {
+        h->keep_a16 = save ? w.x16_e[i] : nullptr;
         AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, h->P + p.bW));
+        h->keep_a16 = nullptr;
+        }
         GruArgs a{};
         a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
@@ -538,8 +555,11 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
             AV_CHECK(id_groups_build(h->stream, ids0, rt, V, w.grp_tgt, save));
             AV_CHECK(rows_gather(h->stream, w.emb_tgt, h->P + h->oE, id_groups_uid(w.grp_tgt, rt, V), cnt, std::min(V, rt), D));
             AV_TRY(gemm(h, false, false, w.emb_tgt, D, h->P + p.W, D, w.ew, 3 * D, std::min(V, rt), 3 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
-        } else
+        } else {
+        h->keep_a16 = save ? w.x16_d[i] : nullptr;
         AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
+        h->keep_a16 = nullptr;
+        }
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
@@ -685,7 +705,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
         } else if (g16) {
             const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
-            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, nullptr, x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, w.x16_kept_d(i), x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr));
             AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, nullptr, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, nullptr));
             float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
             AV_TRY(gemm_bf16_pre(h, w.dgi16_d, 3 * D, false, P + p.W, D, true, dx, D, rt, D, 3 * D, 1.f, 0, 1, nullptr, 0));
@@ -764,7 +784,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
                 fire_hook(h, 2 + 2 * L);
                 hook_flush(h);
             }
-            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, nullptr, x, In, G + p.W, In, Gc, In, rs, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, w.x16_kept_e(i), x, In, G + p.W, In, Gc, In, rs, 1.f, nullptr));
             if (top1) AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));
             for (int d = 0; d < a.njobs; ++d)
                 AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, nullptr));
