@@ -807,6 +807,23 @@ __device__ __forceinline__ TeamMap team_map(const GruArgs& a, int rows_per_block
     return m;
 }
 
+// Padding skipped (GruArgs::slens / perm, optional): slens[slot] = the steps row `slot` really has (its length; decoder: + 1),
+// perm[slot] = the batch row that sits in that slot -- rows sorted by length and dealt over the workgroups by the caller
+// (ops.hip row_order), so that a team's 16 rows are of similar length.  A team runs a row block for
+//     nst = max over its 16 rows of slens (made non-increasing over a workgroup's row blocks by a suffix maximum)
+// steps instead of S; the positions behind them -- padding in both time orientations -- are zero-filled in the row-major
+// outputs (hs / hp forward, dgi / dgh backward: the GEMMs that sum over all rows must meet finite zeros there, as they did
+// when the steps were computed) and never touch the exchange.  All 32 workgroups of a chain group read the same slens, so
+// they agree on every team's step count; any perm is correct, a sorted one is fast.  The exchange scratch is indexed by
+// slot, every external array by perm[slot].
+__device__ __forceinline__ int team_steps(const int* slens, int row0, int lane)
+{
+    int v = slens[row0 + (lane & 15)];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 // PIPE (several row blocks per workgroup): the A fragment of an item is put in flight behind the MFMAs of the item
 // before it (another chain, stored an item ago) and only verified at its own item; !PIPE (one row block: the next
 // item depends on this one's own stores): polled and loaded at the top of the item.  Two instantiations so that each
@@ -914,9 +931,11 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     float hc = 0.f, hc0 = 0.f, hc1 = 0.f, hc2 = 0.f, hc3 = 0.f;      // BF: this thread's h_{t-1} (!PIPE: one row block; PIPE: per row block)
     // byte offset of this lane's first 16-byte piece: step 0 reads the row-major h0 (pieces 64 B apart), later steps
     // the tiled exchange (pieces 1 KB apart); BF: always the exchange, whose slot 0 holds h0
+    const int* const lens_by_slot = a.slens ? a.slens : a.lens;      // (rows permuted: lengths by slot)
+    const int* const perm = a.perm;                                  // slot -> batch row of every external array (nullptr: identity)
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {
         if constexpr (BF) return xch_lane_offset(p == 0 ? 0 : pos_map(p - 1, len_a, J.reverse) + 1, row0, wk * (WK / 8), n, kh, B, D / 2);
-        if (p == 0) return (unsigned)((size_t)(row0 + n) * D * 4) + (wk * WK + 4 * kh) * 4;
+        if (p == 0) return (unsigned)((size_t)(perm ? perm[row0 + n] : row0 + n) * D * 4) + (wk * WK + 4 * kh) * 4;      // (row-major h0: an external array)
         return xch_lane_offset(pos_map(p - 1, len_a, J.reverse), row0, wk * (WK / 4), n, kh, B, D);
     };
     auto q_stride = [&](int p) -> unsigned { return (p == 0 && !BF) ? 64u : 1024u; };
@@ -930,32 +949,57 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         }
     };
     // sequence lengths of the rows this lane touches in the current item (A rows: n, gate rows: tid's row)
-    int len_a = J.reverse ? a.lens[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? a.lens[tm.slot * RB + team * 16 + gr] : 0;
-    const int len_p0 = J.reverse ? a.lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
-    if constexpr (PIPE) next_frag(a.p_begin, 0, len_a);
-    for (int p = a.p_begin; p < a.p_end; ++p) {
-      for (int r = 0; r < tm.nrb; ++r, ++it) {
+    int len_a = J.reverse ? lens_by_slot[tm.slot * RB + team * 16 + n] : 0, len_g = J.reverse ? lens_by_slot[tm.slot * RB + team * 16 + gr] : 0;
+    const int len_p0 = J.reverse ? lens_by_slot[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
+    // steps of this team's row blocks (padding skipped, see team_steps): non-increasing over r
+    int nst0 = a.p_end, nst1 = a.p_end, nst2 = a.p_end, nst3 = a.p_end;
+    if (a.slens) {
+        nst3 = tm.nrb > 3 ? min(a.p_end, team_steps(a.slens, (tm.slot + 3 * tm.cpj) * RB + team * 16, lane)) : 0;
+        nst2 = tm.nrb > 2 ? max(nst3, min(a.p_end, team_steps(a.slens, (tm.slot + 2 * tm.cpj) * RB + team * 16, lane))) : 0;
+        nst1 = tm.nrb > 1 ? max(nst2, min(a.p_end, team_steps(a.slens, (tm.slot + 1 * tm.cpj) * RB + team * 16, lane))) : 0;
+        nst0 = max(nst1, min(a.p_end, team_steps(a.slens, tm.slot * RB + team * 16, lane)));
+    }
+    auto nst_of = [&](int r) -> int { return r == 0 ? nst0 : (r == 1 ? nst1 : (r == 2 ? nst2 : nst3)); };
+    const int p_stop = nst0;                                    // (= a.p_end without slens)
+    int ge_cur = tm.slot * RB + team * 16 + gr;                 // batch row of this thread's gate row in the current item
+    if (perm) ge_cur = perm[ge_cur];
+    if (a.slens && gate_thread) {
+        // positions behind a row block's steps: zeros in the row-major outputs (the GEMMs over all rows read them)
+        for (int r = 0; r < tm.nrb; ++r) {
+            const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
+            for (int p = nst_of(r); p < a.p_end; ++p) {
+                const unsigned rix = (unsigned)p * (unsigned)B + (unsigned)ge;
+                bstore1(0.f, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);
+                if (p_hpw) bstore1(0.f, rs_hpw, (rix * D + j) * 4u);
+            }
+        }
+    }
+    if constexpr (PIPE) { if (a.p_begin < p_stop) next_frag(a.p_begin, 0, len_a); }
+    for (int p = a.p_begin; p < p_stop; ++p) {
+      for (int r = 0; r < tm.nrb && p < nst_of(r); ++r, ++it) {
         TSTAMP(5);
         const int row0 = (tm.slot + r * tm.cpj) * RB + team * 16;     // this team's 16 rows of row block r
         const bool poll = p > a.p_begin && !(ab & 16);            // ablate 16: timing experiment, wrong results
         // (1) exchange-independent loads of the gate phase
-        const int grow = row0 + gr;
+        const int grow = row0 + gr;                               // slot (exchange index); ge_cur: the batch row (external arrays)
         const int gpos = pos_map(p, len_g, J.reverse);
-        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)grow;      // (byte offsets below 2^32: team_geometry checks)
+        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;      // (byte offsets below 2^32: team_geometry checks)
         float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, h0_own = 0.f;
         if (gate_thread) {
             const unsigned grix = p_girows ? (unsigned)p_girows[rix] : rix;          // (table-fed layer: the row of the per-id projection)
             const u32x3 g3 = __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)((grix * (unsigned)a.ldg + ht * 48 + gn * 3) * 4u), 0, 0);
             gi0 = __uint_as_float(g3.x); gi1 = __uint_as_float(g3.y); gi2 = __uint_as_float(g3.z);
-            if constexpr (BF) { if (p == 0 && J.h0 != nullptr) h0_own = bload1(rs_h0, ((unsigned)grow * D + j) * 4u); }
+            if constexpr (BF) { if (p == 0 && J.h0 != nullptr) h0_own = bload1(rs_h0, ((unsigned)ge_cur * D + j) * 4u); }
         }
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
-        const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p + 1;
-        int len2 = len_a, len2g = len_g;
+        const bool same_p = r + 1 < tm.nrb && p < nst_of(r + 1);
+        const int r2 = same_p ? r + 1 : 0, p2 = same_p ? p : p + 1;
+        int len2 = len_a, len2g = len_g, ge2 = ge_cur;
         if constexpr (PIPE) {
-            if (J.reverse && p2 < a.p_end) {
+            if (p2 < p_stop) {
                 const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
-                len2 = a.lens[row2 + n]; len2g = a.lens[row2 + gr];
+                if (J.reverse) { len2 = lens_by_slot[row2 + n]; len2g = lens_by_slot[row2 + gr]; }
+                ge2 = perm ? perm[row2 + gr] : row2 + gr;
             }
         }
         // (2) A operand: this wave's K quarter of the team's 16 rows
@@ -1050,9 +1094,9 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         if constexpr (PIPE) {
             // (every load issued so far is retired HERE, on purpose: hipcc's waitcnt insertion merges the two sides of
             //  the branch below conservatively and would otherwise wait for the new fragment at the first use of gi)
-            asm volatile("" :: "v"(gi0), "v"(gi1), "v"(gi2), "v"(h0_own), "v"(len2), "v"(len2g));
+            asm volatile("" :: "v"(gi0), "v"(gi1), "v"(gi2), "v"(h0_own), "v"(len2), "v"(len2g), "v"(ge2));
             __builtin_amdgcn_sched_barrier(0);
-            if (p2 < a.p_end) next_frag(p2, r2, len2);
+            if (p2 < p_stop) next_frag(p2, r2, len2);
             __builtin_amdgcn_sched_barrier(0);
         }
         TSTAMP(7);
@@ -1091,7 +1135,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             if (p_svw) bstore4(r_, u, nn, gh[2], rs_svw, ((rix * HT + ht) * 64 + gn * 4) * 4u);
             if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
         }
-        len_a = len2; len_g = len2g;
+        len_a = len2; len_g = len2g; ge_cur = ge2;
         TSTAMP(3);
       }
     }
@@ -1464,7 +1508,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     unsigned short* __restrict__ p_dgh16 = BF ? J.dgh16 : nullptr;      // (the bf16 GEMMs' operands as they stand: no conversion pass)
     float* p_dh0 = J.dh0;
     float* p_carry = J.carry;
-    const int* p_lens = a.lens;
+    const int* p_lens = a.slens ? a.slens : a.lens;           // (rows permuted: lengths by slot)
+    const int* const perm = a.perm;                           // slot -> batch row of every external array (nullptr: identity)
     int* p_err = a.err;
     const int j_rev = J.reverse, ldg = a.ldg, ldh = a.ldh;
     float* const xg = a.xbuf + (size_t)tm.jb * S * B * (3 * D) / (BF ? 2 : 1);       // this job's exchange buffer (tiled, sentinel-filled)
@@ -1500,8 +1545,17 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     // across the barrier, the gate math and the loop edge, so the compiler itself must keep their destination
     // registers intact and wait for them before the pass touches hv; beside the asm loads its counted waits can only
     // over-wait
+    // steps of this team's row blocks (padding skipped, see team_steps): non-increasing over r
+    int nst0 = a.p_end, nst1 = a.p_end, nst2 = a.p_end, nst3 = a.p_end;
+    if (a.slens) {
+        nst3 = tm.nrb > 3 ? min(a.p_end, team_steps(a.slens, (tm.slot + 3 * tm.cpj) * RB + team * 16, lane)) : 0;
+        nst2 = tm.nrb > 2 ? max(nst3, min(a.p_end, team_steps(a.slens, (tm.slot + 2 * tm.cpj) * RB + team * 16, lane))) : 0;
+        nst1 = tm.nrb > 1 ? max(nst2, min(a.p_end, team_steps(a.slens, (tm.slot + 1 * tm.cpj) * RB + team * 16, lane))) : 0;
+        nst0 = max(nst1, min(a.p_end, team_steps(a.slens, tm.slot * RB + team * 16, lane)));
+    }
+    auto nst_of = [&](int r) -> int { return r == 0 ? nst0 : (r == 1 ? nst1 : (r == 2 ? nst2 : nst3)); };
     auto next_head = [&](int p2, int r2, int len2) __attribute__((always_inline)) {
-        if (p2 + 1 < S) {
+        if (p2 + 1 < nst_of(r2)) {
             const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
             const unsigned vo2 = a_offset(p2, row2, len2);
 #pragma unroll
@@ -1512,30 +1566,51 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     };
     int len_a = j_rev ? p_lens[tm.slot * RB + team * 16 + n] : 0, len_g = j_rev ? p_lens[tm.slot * RB + team * 16 + gr] : 0;
     const int len_p0 = j_rev ? p_lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
-    if constexpr (PIPE) next_head(a.p_end - 1, 0, len_a);
-    for (int p = a.p_end - 1; p >= p_last; --p, ++done) {
-      for (int r = 0; r < tm.nrb; ++r, ++it) {
+    int ge_cur = tm.slot * RB + team * 16 + gr;                 // batch row of this thread's gate row in the current item
+    if (perm) ge_cur = perm[ge_cur];
+    if (a.slens && gate_thread) {
+        // positions behind a row block's steps: zero gate gradients (the weight-gradient GEMMs sum over every row)
+        for (int r = 0; r < tm.nrb; ++r) {
+            const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
+            for (int p = nst_of(r); p < a.p_end; ++p) {
+                const unsigned orow = (((unsigned)p * (unsigned)B + (unsigned)ge) * (unsigned)ldg + ht * 48 + gn * 3) * 4u;
+                if (BF && p_dgi16 != nullptr) {
+                    if ((gn & 1) == 0) {
+                        const u32x3 z3 = {0u, 0u, 0u};
+                        __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgh16, (int)(orow >> 1), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgi16, (int)(orow >> 1), 0, 0);
+                    }
+                } else { bstore3(0.f, 0.f, 0.f, rs_dghw, orow); bstore3(0.f, 0.f, 0.f, rs_dgi, orow); }
+            }
+        }
+    }
+    const int p_first = nst0 - 1;                               // (= a.p_end - 1 without slens)
+    if constexpr (PIPE) next_head(p_first, 0, len_a);
+    for (int p = p_first; p >= p_last; --p, ++done) {
+      for (int r = 0; r < tm.nrb && (p < 0 || p < nst_of(r)); ++r, ++it) {
         const int row0 = (tm.slot + r * tm.cpj) * RB + team * 16;
         // (the compiler would otherwise keep a dozen loop-invariant 64-bit per-lane addresses alive across the MFMA
         //  phase and spill them at 128 VGPRs; hidden behind an empty asm the lane's unit / row are re-derived per item)
         int gn_l = gn, gr_l = gr, ln_l = lane;
         asm volatile("" : "+v"(gn_l), "+v"(gr_l), "+v"(ln_l));
-        const int grow = row0 + gr_l, j_l = ht * 16 + gn_l;
-        const bool have_next = p + 1 < S;
+        const int grow = row0 + gr_l, j_l = ht * 16 + gn_l;       // grow: slot (exchange, carry scratch); ge_cur: the batch row
+        const bool have_next = p + 1 < nst_of(r);
         const bool poll = done > 0 && !(DIAG && (a.ablate & 16));      // ablate 16 (diagnostic build): no waiting, wrong results
         // PIPE: the item after this one (its row lengths are fetched now, long before they are needed)
-        const int r2 = (r + 1 < tm.nrb) ? r + 1 : 0, p2 = (r + 1 < tm.nrb) ? p : p - 1;
-        int len2 = len_a, len2g = len_g;
+        const bool same_p = r + 1 < tm.nrb && (p < 0 || p < nst_of(r + 1));
+        const int r2 = same_p ? r + 1 : 0, p2 = same_p ? p : p - 1;
+        int len2 = len_a, len2g = len_g, ge2 = ge_cur;
         if constexpr (PIPE) {
-            if (j_rev && p2 >= p_last) {
+            if (p2 >= p_last) {
                 const int row2 = (tm.slot + r2 * tm.cpj) * RB + team * 16;
-                len2 = p_lens[row2 + n]; len2g = p_lens[row2 + gr];
+                if (j_rev) { len2 = p_lens[row2 + n]; len2g = p_lens[row2 + gr]; }
+                ge2 = perm ? perm[row2 + gr] : row2 + gr;
             }
         }
         BSTAMP(7);
         // (1) exchange-independent loads of the gate phase
         const int gpos = pos_map(p < 0 ? 0 : p, len_g, j_rev);
-        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)grow;      // (byte offsets below 2^32: team_geometry checks)
+        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;      // (byte offsets below 2^32: team_geometry checks)
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
         if (p >= 0 && gate_thread) {
             sv = bload4(rs_sv, ((rix * HT + ht) * 64 + gn_l * 4) * 4u);
@@ -1641,7 +1716,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         // flight now, behind the team barrier and the gate math (the pass still checks every dword)
         if constexpr (PIPE) {
             // (the loads of the gate phase are retired HERE, on purpose: see the forward)
-            asm volatile("" :: "v"(sv.x), "v"(sv.y), "v"(sv.z), "v"(sv.w), "v"(s_hp), "v"(s_do), "v"(s_carry), "v"(len2), "v"(len2g));
+            asm volatile("" :: "v"(sv.x), "v"(sv.y), "v"(sv.z), "v"(sv.w), "v"(s_hp), "v"(s_do), "v"(s_carry), "v"(len2), "v"(len2g), "v"(ge2));
             __builtin_amdgcn_sched_barrier(0);
             if (p2 >= p_last) next_head(p2, r2, len2);
             __builtin_amdgcn_sched_barrier(0);
@@ -1663,7 +1738,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             float carried = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             if constexpr (PIPE) carried += s_carry;
             else if (have_next) carried += carry_reg;
-            if (p < 0) { p_dh0[(size_t)grow * D + j_l] = carried; len_a = len2; len_g = len2g; continue; }
+            if (p < 0) { p_dh0[(size_t)ge_cur * D + j_l] = carried; len_a = len2; len_g = len2g; ge_cur = ge2; continue; }
             const float dH = carried + s_do;
             const float r_ = sv.x, u = sv.y, nn = sv.z;
             const float dn = dH * (1.f - u) * (1.f - nn * nn);
@@ -1710,7 +1785,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             }
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
-        len_a = len2; len_g = len2g;
+        len_a = len2; len_g = len2g; ge_cur = ge2;
         BSTAMP(6);
       }
     }
@@ -1871,7 +1946,7 @@ __global__ __launch_bounds__(256) void gru_prepare_kernel(unsigned* sync_words, 
 // to bf16 in the tiled order of xch16_index, and S sentinel-filled slots behind it
 struct GruH0 { const float* p[kMaxGruJobs]; };
 __global__ __launch_bounds__(256) void gru_prepare16_kernel(unsigned* sync_words, int nsync, uint4* buf, size_t n16, size_t chunks_per_job,
-                                                            size_t seed_chunks, GruH0 h0s, int D)
+                                                            size_t seed_chunks, GruH0 h0s, int D, const int* perm)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1885,7 +1960,7 @@ __global__ __launch_bounds__(256) void gru_prepare16_kernel(unsigned* sync_words
             const float* h0 = h0s.p[job];
             if (h0) {
                 const size_t rb = c / ((size_t)(D >> 3) * 16), rem = c - rb * ((size_t)(D >> 3) * 16);
-                const size_t k8 = rem >> 4, row = rb * 16 + (rem & 15);
+                const size_t k8 = rem >> 4, slot = rb * 16 + (rem & 15), row = perm ? (size_t)perm[slot] : slot;      // (h0 is an external array)
                 const float4 a0 = *reinterpret_cast<const float4*>(h0 + row * D + k8 * 8), a1 = *reinterpret_cast<const float4*>(h0 + row * D + k8 * 8 + 4);
                 v = make_uint4(pack_bf16(a0.x, a0.y), pack_bf16(a0.z, a0.w), pack_bf16(a1.x, a1.y), pack_bf16(a1.z, a1.w));
             }
@@ -1908,7 +1983,7 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd, b
         for (int i = 0; i < a.njobs; ++i) h0s.p[i] = a.job[i].h0;
         const size_t chunks_per_job = ((size_t)a.S + 1) * a.B * a.D / 8;
         hipLaunchKernelGGL(gru_prepare16_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords, reinterpret_cast<uint4*>(a.xbuf),
-                           (size_t)a.njobs * chunks_per_job, chunks_per_job, (size_t)a.B * a.D / 8, h0s, a.D);
+                           (size_t)a.njobs * chunks_per_job, chunks_per_job, (size_t)a.B * a.D / 8, h0s, a.D, a.perm);
         return hipGetLastError();
     }
     if (team) {       // team kernels exchange through the tiled scratch buffer: one linear fill over every job's part
@@ -2039,6 +2114,14 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     return hipSuccess;
 }
 
+bool gru_team_shape(const GruArgs& a, bool fwd, bool persistent, int* T, int* cpj, int* nrb)
+{
+    int C = 0;
+    if (fwd ? !forward_team(a, persistent, T, &C) : !(persistent && team_geometry(a, false, T, &C) && !a.ablate && a.item_pipeline == 2)) return false;
+    *cpj = C / a.njobs;
+    *nrb = (a.B / (16 * *T)) / *cpj;
+    return *cpj >= 1 && *nrb >= 1 && *nrb <= 4;
+}
 bool gru_backward_uses_team(const GruArgs& a, bool persistent)
 {
     int T = 0, C = 0;

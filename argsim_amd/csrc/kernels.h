@@ -82,6 +82,10 @@ struct GruArgs {
     GruJob job[kMaxGruJobs];
     int njobs, S, B, D, ldg, ldh;
     const int* lens;      // (B) or nullptr
+    // optional, team kernels only (gru.hip "Padding skipped"): steps each SLOT really has and the batch row sitting in it;
+    // both or neither.  The other kernel forms ignore them and run every step of every row.
+    const int* slens;     // (B) by slot
+    const int* perm;      // (B) slot -> batch row
     int G;                // batch groups per job
     int rows_per_group;   // multiple of 16
     int p_begin, p_end;   // steps [p_begin, p_end) of this launch
@@ -99,6 +103,9 @@ struct GruArgs {
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
 bool gru_forward_uses_team(const GruArgs& a, bool persistent);      // true: the launch runs the LDS-weight team kernels (gi_rows honoured)
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
+// geometry of the team kernels a launch of this shape would run: T teams of 16 rows per 16 T-row block, cpj chain groups
+// (workgroups) per job and hidden tile, nrb row blocks per workgroup; false: another kernel form runs (no slens / perm)
+bool gru_team_shape(const GruArgs& a, bool fwd, bool persistent, int* T, int* cpj, int* nrb);
 bool gru_backward_uses_team(const GruArgs& a, bool persistent);     // true: the launch runs the LDS-weight team kernels (dgi16 / dgh16 honoured in bf16 mode)
 bool gru_dim_supported(int D);
 // one GRU step from a zero state for B rows (the top encoder layer's backward direction: gru.hip "one step from a zero
@@ -144,6 +151,12 @@ hipError_t rows_gather_ranked(hipStream_t st, float* dst, const float* src, cons
 hipError_t rows_group_sum(hipStream_t st, float* dst, const int32_t* ids, const float* src, int n, int W, int V, int32_t* scratch);
 hipError_t rows_add_indexed(hipStream_t st, float* dst, const float* src, const int32_t* uid, const int32_t* nuniq, int n_max, int D);
 inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 + n + (n / 32 + V + 1); }
+// Row order for the padding-skipping team kernels: rows sorted by steps[b] = lens[b] + add (descending, stable) and dealt
+// in groups of 16 over the workgroups of a (T, cpj) team geometry so that every workgroup's row blocks get shorter with r
+// (slot of sorted group g: ((g % cpj) + (g / cpj / T) * cpj) * T + (g / cpj) % T).  perm[slot] = batch row, slens[slot] =
+// its steps.  Up to three geometries in one launch.
+struct RowOrder { const int32_t* lens; int add, T, cpj; int32_t* perm; int32_t* slens; };
+hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S);
 // dst[i,:] = src[idx[i],:] for i < *n_dev
 hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);
 // dst[r,:] = rank[r] >= 0 ? src[rank[r],:] : 0   for r < rows

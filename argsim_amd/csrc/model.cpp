@@ -49,6 +49,7 @@ struct avae_ctx {
     int persistent = 1;
     bool first_step_checked = false;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int skip_pad = 1;     // team GRU kernels skip the steps behind a row block's longest row (rows sorted by length, ops.hip row_order); 0: every step of every row
     int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
@@ -143,6 +144,9 @@ struct Ws {
     int32_t *grp_src, *grp_tgt;           // id_groups_build scratch of the two id sources (use_table)
     int32_t *tokrow_src, *tokrow_tgt;
     float* xbuf; size_t xbuf_floats;      // exchange scratch of the GRU team kernels (GruArgs::xbuf)
+    // row orders of the padding-skipping team kernels (build_row_orders): 0 = encoder, both directions; 1 = encoder, one job
+    // (top layer); 2 = decoder.  ord_ok: built for this call with geometry (ord_T, ord_cpj)
+    int32_t *ord_perm[3], *ord_slens[3]; int ord_T[3], ord_cpj[3]; bool ord_ok[3];
 };
 
 struct Bump {
@@ -204,6 +208,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.xbuf_floats = rows * D * (train ? 3 : 1);
         w.xbuf = b.take<float>(w.xbuf_floats);
     }
+    for (int k = 0; k < 3; ++k) { w.ord_perm[k] = b.take<int32_t>(B); w.ord_slens[k] = b.take<int32_t>(B); w.ord_ok[k] = false; w.ord_T[k] = w.ord_cpj[k] = 0; }
     w.hpick = b.take<float>((size_t)B * 2 * D);
     w.xlast = b.take<float>((size_t)B * 2 * D); w.gib = b.take<float>((size_t)B * 3 * D); w.svb = b.take<float>((size_t)B * 4 * D);
     w.dgib = b.take<float>(train ? (size_t)B * 3 * D : 0); w.dghb = b.take<float>(train ? (size_t)B * 3 * D : 0); w.dxl = b.take<float>(train ? (size_t)B * 2 * D : 0);
@@ -471,6 +476,48 @@ Sched schedule(const avae_ctx* h)
 static bool top_one_step(const avae_ctx* h) { return h->enc_top1 && h->cfg.rnn_layers >= 2; }
 
 // -------------------------------------------------------------------------------- forward pieces
+// GRU launch arguments common to every call site
+static void gru_common(avae_ctx* h, const Ws& w, GruArgs& a, int njobs, int S, int B, int ldg, int ldh, const int32_t* lens)
+{
+    const int D = h->cfg.dim_emb;
+    a.njobs = njobs; a.S = S; a.B = B; a.D = D; a.ldg = ldg; a.ldh = ldh; a.lens = lens;
+    gru_geometry(D, njobs, B, &a.G, &a.rows_per_group);
+    a.p_begin = 0; a.p_end = S; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow;
+    a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item;
+    a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+}
+// Row orders of this call (one launch, after prep_ids has the lengths): for every GRU launch shape of the step whose team
+// kernels can skip padding, the batch rows sorted by length and dealt over the workgroups.  with_dec: the decoder runs too.
+int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
+{
+    if (!h->skip_pad || !h->persistent || B % 16) return 0;
+    const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
+    RowOrder ord[3]; int n = 0, which[3];
+    auto want = [&](int k, int njobs, int S, int ldg, int ldh, const int32_t* lens, int add) {
+        GruArgs a{};
+        gru_common(h, w, a, njobs, S, B, ldg, ldh, lens);
+        int Tm = 0, cpj = 0, nrb = 0;
+        if (S < 2 || !gru_team_shape(a, true, true, &Tm, &cpj, &nrb)) return;
+        ord[n] = RowOrder{lens, add, Tm, cpj, w.ord_perm[k], w.ord_slens[k]};
+        which[n++] = k; w.ord_T[k] = Tm; w.ord_cpj[k] = cpj;
+    };
+    if (!top_one_step(h) || L >= 2) want(0, 2, Ss, 6 * D, 2 * D, w.lens_src, 0);
+    if (top_one_step(h)) want(1, 1, Ss, 6 * D, 2 * D, w.lens_src, 0);
+    if (with_dec) want(2, 1, T, 3 * D, D, w.lens_tgt, 1);
+    if (!n) return 0;
+    hipError_t e = row_order(h->stream, ord, n, B, std::max(Ss, T));
+    if (e == hipErrorInvalidValue) return 0;                 // (a batch beyond the kernel's LDS: no order, every step runs)
+    AV_CHECK(e);
+    for (int i = 0; i < n; ++i) w.ord_ok[which[i]] = true;
+    return 0;
+}
+static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
+{
+    int T = 0, cpj = 0, nrb = 0;
+    if (!w.ord_ok[k] || !gru_team_shape(a, fwd, h->persistent != 0, &T, &cpj, &nrb) || T != w.ord_T[k] || cpj != w.ord_cpj[k]) return;
+    a.slens = w.ord_slens[k]; a.perm = w.ord_perm[k];
+}
+
 int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 {
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
@@ -513,6 +560,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             j.hp = save ? w.e_hp[d][i] : nullptr;
             j.reverse = d;
         }
+        attach_order(h, w, a, true, top1 ? 1 : 0);
         { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         if (top1) {
@@ -575,6 +623,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         j.sv = save ? w.d_sv[i] : nullptr;
         j.hp = save ? w.d_hp[i] : nullptr;
         j.reverse = 0;
+        if (T > 1) attach_order(h, w, a, true, 2);
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.d_hd[i];
@@ -594,6 +643,7 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
     p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4; p.zero2 = h->acc;
     AV_CHECK(prep_ids(h->stream, p));
+    AV_TRY(build_row_orders(h, w, B, Ss, T, true));
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
     AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
@@ -691,6 +741,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         // (a table-fed layer keeps fp32: its gradients are summed by id first)
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) { j.dgi16 = w.dgi16_d; j.dgh16 = w.dgh16_d; }
+        attach_order(h, w, a, false, 2);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -768,6 +819,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         }
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) for (int d = 0; d < a.njobs; ++d) { a.job[d].dgi16 = w.dgi16_e + d * 3 * D; a.job[d].dgh16 = w.dgh16_e + d * 3 * D; }
+        attach_order(h, w, a, false, top1 ? 1 : 0);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -1063,6 +1115,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
     if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
     if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }
+    if (!strcmp(key, "skip_pad")) { h->skip_pad = value != 0; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");
@@ -1254,6 +1307,7 @@ int avae_encode(avae_handle h, const int32_t* src, int32_t b, int32_t t, float* 
     p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4;
     // tgt is unused by the encoder; feed the first column of src as a 1-wide dummy target
     AV_CHECK(prep_ids(h->stream, p));
+    AV_TRY(build_row_orders(h, w, b, t, 2, false));
     AV_TRY(run_encoder(h, w, b, t, false));
     AV_TRY(run_latent(h, w, b, false, 0, nullptr));
     const size_t n = (size_t)b * h->cfg.dim_rep * sizeof(float);

@@ -492,6 +492,34 @@ hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32
 }
 
 // ---------------------------------------------------------------- final-state pick (tf.gather_nd, model.py:135)
+// ---------------------------------------------------------------- row order for the padding-skipping GRU kernels
+struct RowOrders { RowOrder o[3]; };
+__global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int B, int S)
+{
+    extern __shared__ int steps[];                       // B ints
+    const RowOrder o = ro.o[blockIdx.x];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) steps[b] = min(max(o.lens[b] + o.add, 1), S);
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int mine = steps[b];
+        int rank = 0;                                     // rows with more steps, or as many and a smaller index: stable, descending
+        for (int c = 0; c < B; ++c) { const int v = steps[c]; rank += (v > mine) || (v == mine && c < b); }
+        const int g = rank >> 4, w = g % o.cpj, jj = g / o.cpj;
+        const int slot = (((w + (jj / o.T) * o.cpj) * o.T + jj % o.T) << 4) + (rank & 15);
+        o.perm[slot] = b;
+        o.slens[slot] = mine;
+    }
+}
+hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S)
+{
+    if (n <= 0) return hipSuccess;
+    if (n > 3 || B % 16 || (size_t)B * 4 > 64 * 1024) return hipErrorInvalidValue;
+    RowOrders ro{};
+    for (int i = 0; i < n; ++i) ro.o[i] = orders[i];
+    hipLaunchKernelGGL(row_order_kernel, dim3(n), dim3(1024), (size_t)B * sizeof(int), st, ro, B, S);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void pick_last_kernel(float* __restrict__ h, const float* __restrict__ hs,
                                                         const int32_t* __restrict__ lens, int B, int W)
 {

@@ -255,3 +255,37 @@ def test_bf16_tn_gemm_reads_row_major_operands(M, N, K):
     err = float((Cm.double() - ref).abs().max())
     assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err          # fp32 accumulation over K products of O(1/4)
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ padding skipped in the recurrence
+@pytest.mark.parametrize("B,S,dtype", [(256, 64, 'f32'), (64, 40, 'f32'), (512, 24, 'f32'), (1024, 20, 'f32'), (512, 24, 'bf16')])
+def test_padding_skipped_in_the_team_kernels_changes_nothing(B, S, dtype):
+    """"outputs at t >= len_b ... provably never reach z or the loss -- the build may skip or zero them".
+    Default path: rows sorted by length and dealt over the workgroups (row_order), every team runs its row block for the
+    steps of its longest row only, the positions behind are zero-filled (option skip_pad) -- against the same library
+    running every step of every row (skip_pad = 0), on RAGGED LogNormal batches: one row block per workgroup (B = 256, 64),
+    two and four pipelined row blocks (B = 512, 1024), fp32 and the 16-bit exchange.  A row's arithmetic does not depend
+    on which team it sits in: z and the per-token losses bit for bit (fp32), gradients up to float-atomic order."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=1, dtype=dtype, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    ids = synth.batch(B, S, 8192, ragged=True, seed=7)
+    ids[3, 1:] = 1                                   # a one-token row
+    out = {}
+    for skip in (1, 0):
+        m.set_option('skip_pad', skip)
+        z = m.encode(ids)
+        ev = m.eval(ids, ids)
+        m.forward_backward(ids, ids, seed=5)
+        out[skip] = (z, ev, m.grads.clone(), m.losses())
+    if dtype == 'f32':
+        assert np.array_equal(out[1][0], out[0][0])
+        for x, y in zip(out[1][1], out[0][1]):
+            assert np.array_equal(x, y)
+    else:                                            # bf16 gate gradients: the same values, summed by the GEMMs in the same order
+        assert np.array_equal(out[1][0], out[0][0])
+    d = float((out[1][2] - out[0][2]).norm() / out[0][2].norm())
+    assert d < 1e-5, d
+    assert all(np.isfinite(out[1][3]))
+    m.close()
