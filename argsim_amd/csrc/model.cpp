@@ -1412,7 +1412,7 @@ int avae_decode_greedy(avae_handle h, const float* z, int32_t b, int32_t steps, 
     AV_TRY(check_bound(h));
     if (b < 1 || steps < 1) return fail(h, "empty batch");
     AV_CHECK(hipSetDevice(h->device));
-    // measured at D = 512, V = 8192, steps = 512 (scripts/decode_bench.py, gpurun_out/decode4.log): the persistent launch
+    // measured at D = 512, V = 8192, steps = 512 (scripts/decode_bench.py, profiles/r03_decode_bench.txt): the persistent launch
     // takes 42 / 74 / 145 us per token at b = 1 / 16 / 64, the launch-per-token loop 116-130 us at any b <= 128 (its
     // GEMMs are far from full): one launch up to 32 rows, the per-token loop above
     if (!h->persistent || b > 32) return decode_greedy_stepwise(h, z, b, steps, out_ids, n_steps);
