@@ -194,6 +194,7 @@ hipError_t argmax_rows(hipStream_t st, const float* logits, int32_t* pred, int n
 // out[n] (+)= sum_m X[m, n]
 hipError_t colsum(hipStream_t st, const float* X, int M, int N, int ldx, float* out, const int32_t* m_dev);
 hipError_t add3(hipStream_t st, float* out, const float* a, const float* b, const float* c, int64_t n);
+hipError_t zero_fill(hipStream_t st, void* p, size_t bytes);      // a plain kernel instead of the runtime's blit (16-byte aligned p, bytes % 4 == 0)
 
 struct AdamArgs { float* p; const float* g; float* m; float* v; int64_t n; float lr_t, b1, b2, eps;
                   const int* skip_if; };   // device word: non-zero -> the update is a no-op (GRU time-out flag)

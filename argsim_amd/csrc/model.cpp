@@ -375,7 +375,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
         if (allow_atomic && !accumulate && ldc == N && K >= 512) {
             int s = std::min(768 / tiles, K / 128);
             if (s >= 2) {
-                AV_CHECK(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, h->stream));
+                AV_CHECK(zero_fill(h->stream, C, sizeof(float) * (size_t)M * N));
                 return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, 0, s, dyn, dyn_kind);
             }
         }
@@ -404,7 +404,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
                 // K split over ~768 workgroups of full tiles with float atomics instead
                 const int s = std::min(768 / (((tail_rows + 127) / 128) * nt), K / 128);
                 if (s >= 2) {
-                    AV_CHECK(hipMemsetAsync(Ct, 0, sizeof(float) * (size_t)tail_rows * N, h->stream));
+                    AV_CHECK(zero_fill(h->stream, Ct, sizeof(float) * (size_t)tail_rows * N));
                     return gemm_raw(h, a_mc, b_nc, At, lda, Bm, ldb, Ct, ldc, tail_rows, N, K, alpha, bias, 0, s, nullptr, 0);
                 }
             }
@@ -699,7 +699,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     hipStream_t st = h->stream;
     float* G = h->G; const float* P = h->P;
     h->hook_pending.clear();
-    AV_CHECK(hipMemsetAsync(G, 0, sizeof(float) * h->numel, st));
+    AV_CHECK(zero_fill(st, G, sizeof(float) * h->numel));
 
     // logits: dho = dlogits E / sqrt(D);  dE = dlogits^T ho / sqrt(D)
     if (h->cfg.compute_dtype == 1 && (V & 7) == 0) {

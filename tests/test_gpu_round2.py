@@ -135,8 +135,11 @@ def test_production_kernels_seq128_bf16_tolerance():
         lo = m.losses()[2]
         assert abs(lo - float(gold['loss'])) <= tl * abs(float(gold['loss'])), dtype
         for k, g in m.get_grads().items():
+            g = g.astype(np.float64)
             n = float(gold['gnorm/' + k])
-            assert abs(np.linalg.norm(g.astype(np.float64)) - n) <= tg * n, (dtype, k)
+            assert abs(np.linalg.norm(g) - n) <= tg * n, (dtype, k)
+            p = _probe(k, g.shape)              # one fixed random projection per variable (the fixture's gdot/*)
+            assert abs(float((g * p).sum()) - float(gold['gdot/' + k])) <= tg * n * np.linalg.norm(p), (dtype, k)
         m.close()
 
 

@@ -289,3 +289,27 @@ def test_padding_skipped_in_the_team_kernels_changes_nothing(B, S, dtype):
     assert d < 1e-5, d
     assert all(np.isfinite(out[1][3]))
     m.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 512), (4100, 3080, 1024), (4096, 4096, 96)])
+def test_bf16_nt_gemm_large_tile_form(M, N, K):
+    """compute_dtype 1, C = A B^T + bias on the 256x256 tile kernel (fp32 operands converted to bf16 panels first), against
+    torch on the same bf16-rounded operands in float64; edge tiles in M and N, a K that is no multiple of the 64-deep tile."""
+    import ctypes as C
+    import torch
+    from argsim_amd.model import VAE
+    m = VAE('train', dtype='bf16', dim_tgt=64, dim_emb=16, dim_rep=8, rnn_layers=1)
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn((M, K), device='cuda', generator=g) * 0.5
+    B = torch.randn((N, K), device='cuda', generator=g) * 0.5
+    bias = torch.randn((N,), device='cuda', generator=g)
+    Cm = torch.zeros((M, N), device='cuda')
+    m._stream()
+    rc = m._l.avae_debug_gemm(m._h, 0, 0, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), C.c_void_p(bias.data_ptr()),
+                              M, N, K, K, K, N, 0.5, 0, 1)
+    assert rc == 0, m._l.avae_last_error(m._h)
+    torch.cuda.synchronize()
+    ref = 0.5 * (A.bfloat16().double() @ B.bfloat16().double().t()) + bias.double()
+    err = float((Cm.double() - ref).abs().max())
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
+    m.close()
