@@ -1132,7 +1132,13 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 if (fast) bstore1(not_sentinel(hnew), rs_hs, xo); else bstore1_sc1(not_sentinel(hnew), rs_hs, xo);
             }
             bstore1(hnew, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);       // the row-major copy the GEMMs and the next layer read
-            if (p_svw) bstore4(r_, u, nn, gh[2], rs_svw, ((rix * HT + ht) * 64 + gn * 4) * 4u);
+            if (p_svw) {
+                if (BF && a.sv16) {     // saved gates as bf16 (same index in halfwords): half the bytes here and in the BPTT's reads
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 s2 = {pack_bf16(r_, u), pack_bf16(nn, gh[2])};
+                    __builtin_amdgcn_raw_buffer_store_b64(s2, rs_svw, (int)(((rix * HT + ht) * 64 + gn * 4) * 2u), 0, 0);
+                } else bstore4(r_, u, nn, gh[2], rs_svw, ((rix * HT + ht) * 64 + gn * 4) * 4u);
+            }
             if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
         }
         len_a = len2; len_g = len2g; ge_cur = ge2;
@@ -1613,6 +1619,11 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;      // (byte offsets below 2^32: team_geometry checks)
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
         if (p >= 0 && gate_thread) {
+            if (BF && a.sv16) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 s2 = __builtin_amdgcn_raw_buffer_load_b64(rs_sv, (int)(((rix * HT + ht) * 64 + gn_l * 4) * 2u), 0, 0);
+                sv = make_float4(__uint_as_float(s2.x << 16), __uint_as_float(s2.x & 0xffff0000u), __uint_as_float(s2.y << 16), __uint_as_float(s2.y & 0xffff0000u));
+            } else
             sv = bload4(rs_sv, ((rix * HT + ht) * 64 + gn_l * 4) * 4u);
             s_hp = bload1(rs_hp, (rix * D + j_l) * 4u);
             s_do = p_do ? bload1(rs_do, (rix * (unsigned)ldh + j_l) * 4u) : 0.f;
@@ -2077,6 +2088,7 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
     int T = 0, C = 0;
     const bool team = forward_team(a, persistent, &T, &C);
+    if (a.sv16 && !(team && a.bf16)) return hipErrorInvalidValue;      // 16-bit saved gates: the bf16 team kernels only
     for (int i = 0; i < a.njobs; ++i) if (a.job[i].gi_rows && !team) return hipErrorInvalidValue;      // only the team kernels index gi through gi_rows
     if (persistent && a.p_end - a.p_begin > 1) {
         // D = 512: independent 16-row teams sharing one LDS-resident weight slice per CU, the row blocks of a workgroup
@@ -2130,6 +2142,7 @@ bool gru_backward_uses_team(const GruArgs& a, bool persistent)
 
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
 {
+    if (a.sv16 && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
     for (int i = 0; i < a.njobs; ++i)      // 16-bit gate gradients are written by the bf16 team kernels only
         if ((a.job[i].dgi16 || a.job[i].dgh16) && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
 

@@ -97,6 +97,7 @@ struct GruArgs {
     size_t xbuf_floats;   // njobs*S*B*D floats (forward) / njobs*S*B*3D (backward); nullptr / too small: register-form kernels
     int stagger;          // 1: delay the second half of the grid by ~half a step (co-resident chains de-phased)
     int force_slow;       // 1: never use the same-XCD L2 fast path
+    int sv16;             // 1 (bf16 team kernels, forward AND backward of a layer): the saved gates r, u, n, hn are stored as bf16
     int bf16;             // 1 (compute_dtype 1): the team kernels round both operands of the recurrent product to bf16
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };

@@ -53,6 +53,7 @@ struct avae_ctx {
     int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
+    int bf16_sv = 1;      // compute_dtype 1: saved gates as bf16 where a layer's forward and backward both run the team kernels
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
@@ -512,6 +513,15 @@ int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
     for (int i = 0; i < n; ++i) w.ord_ok[which[i]] = true;
     return 0;
 }
+// bf16 mode: a layer whose forward AND backward launches both run the bf16 team kernels keeps its saved gates as bf16
+static void attach_sv16(avae_ctx* h, GruArgs& a, bool train)
+{
+    int T = 0, cpj = 0, nrb = 0;
+    GruArgs q = a; q.sv16 = 0; q.slens = nullptr; q.perm = nullptr;
+    for (int i = 0; i < q.njobs; ++i) { q.job[i].dgi16 = nullptr; q.job[i].dgh16 = nullptr; q.job[i].gi_rows = nullptr; }
+    q.p_begin = 0; q.p_end = q.S;
+    a.sv16 = train && h->bf16_sv && a.bf16 && a.S > 1 && gru_team_shape(q, true, h->persistent != 0, &T, &cpj, &nrb) && gru_team_shape(q, false, h->persistent != 0, &T, &cpj, &nrb);
+}
 static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
 {
     int T = 0, cpj = 0, nrb = 0;
@@ -561,6 +571,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             j.hp = save ? w.e_hp[d][i] : nullptr;
             j.reverse = d;
         }
+        attach_sv16(h, a, save);
         attach_order(h, w, a, true, top1 ? 1 : 0);
         { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
@@ -624,6 +635,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         j.sv = save ? w.d_sv[i] : nullptr;
         j.hp = save ? w.d_hp[i] : nullptr;
         j.reverse = 0;
+        attach_sv16(h, a, save);
         if (T > 1) attach_order(h, w, a, true, 2);
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
@@ -742,6 +754,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         // (a table-fed layer keeps fp32: its gradients are summed by id first)
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) { j.dgi16 = w.dgi16_d; j.dgh16 = w.dgh16_d; }
+        attach_sv16(h, a, true);
         attach_order(h, w, a, false, 2);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
@@ -820,6 +833,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         }
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) for (int d = 0; d < a.njobs; ++d) { a.job[d].dgi16 = w.dgi16_e + d * 3 * D; a.job[d].dgh16 = w.dgh16_e + d * 3 * D; }
+        attach_sv16(h, a, true);
         attach_order(h, w, a, false, top1 ? 1 : 0);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
@@ -1113,6 +1127,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
+    if (!strcmp(key, "bf16_sv")) { h->bf16_sv = value != 0; return 0; }
     if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
     if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
     if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }
