@@ -900,6 +900,13 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(xh), rs_h0 = make_rsrc(J.h0 ? J.h0 : xh);
     const __amdgpu_buffer_rsrc_t rs_gi = make_rsrc(p_gi), rs_hsw = make_rsrc(p_hsw);
     const __amdgpu_buffer_rsrc_t rs_svw = make_rsrc(p_svw ? p_svw : p_hsw), rs_hpw = make_rsrc(p_hpw ? p_hpw : p_hsw);
+    // bf16 mode: the row-major h / h_prev copies as bf16 INSTEAD of fp32 where the caller gave 16-bit arrays (the next layer's
+    // GEMM operand and the dR GEMM's operand as they stand: no conversion pass, half the bytes)
+    unsigned short* __restrict__ p_hs16 = BF ? J.hs16 : nullptr;
+    unsigned short* __restrict__ p_hp16 = BF ? J.hp16 : nullptr;
+    const __amdgpu_buffer_rsrc_t rs_hs16 = make_rsrc(reinterpret_cast<const float*>(p_hs16 ? p_hs16 : reinterpret_cast<unsigned short*>(p_hsw)));
+    const __amdgpu_buffer_rsrc_t rs_hp16 = make_rsrc(reinterpret_cast<const float*>(p_hp16 ? p_hp16 : reinterpret_cast<unsigned short*>(p_hsw)));
+    auto to_bf16 = [](float v) -> unsigned short { return (unsigned short)(pack_bf16(v, 0.f) & 0xffffu); };
     const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
     float* tpart = part + team * (KS * 3 * 256);
     float* thps = hps + team * 256;
@@ -969,8 +976,10 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
             for (int p = nst_of(r); p < a.p_end; ++p) {
                 const unsigned rix = (unsigned)p * (unsigned)B + (unsigned)ge;
-                bstore1(0.f, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);
-                if (p_hpw) bstore1(0.f, rs_hpw, (rix * D + j) * 4u);
+                if (BF && p_hs16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rs_hs16, (int)((rix * (unsigned)a.ldh + j) * 2u), 0, 0);
+                else bstore1(0.f, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);
+                if (BF && p_hp16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rs_hp16, (int)((rix * D + j) * 2u), 0, 0);
+                else if (p_hpw) bstore1(0.f, rs_hpw, (rix * D + j) * 4u);
             }
         }
     }
@@ -1131,7 +1140,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 const unsigned xo = xch_index(gpos, grow, j, B, D) * 4u;      // exchanged store first
                 if (fast) bstore1(not_sentinel(hnew), rs_hs, xo); else bstore1_sc1(not_sentinel(hnew), rs_hs, xo);
             }
-            bstore1(hnew, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);       // the row-major copy the GEMMs and the next layer read
+            if (BF && p_hs16) __builtin_amdgcn_raw_buffer_store_b16(to_bf16(hnew), rs_hs16, (int)((rix * (unsigned)a.ldh + j) * 2u), 0, 0);
+            else bstore1(hnew, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);       // the row-major copy the GEMMs and the next layer read
             if (p_svw) {
                 if (BF && a.sv16) {     // saved gates as bf16 (same index in halfwords): half the bytes here and in the BPTT's reads
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -1139,7 +1149,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                     __builtin_amdgcn_raw_buffer_store_b64(s2, rs_svw, (int)(((rix * HT + ht) * 64 + gn * 4) * 2u), 0, 0);
                 } else bstore4(r_, u, nn, gh[2], rs_svw, ((rix * HT + ht) * 64 + gn * 4) * 4u);
             }
-            if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
+            if (BF && p_hp16) __builtin_amdgcn_raw_buffer_store_b16(to_bf16(hprev), rs_hp16, (int)((rix * D + j) * 2u), 0, 0);
+            else if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
         }
         len_a = len2; len_g = len2g; ge_cur = ge2;
         TSTAMP(3);
@@ -1531,6 +1542,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     u32x4 hv[NB][PQ];                                         // ring of A-operand pieces
     const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(xg);
     const __amdgpu_buffer_rsrc_t rs_sv = make_rsrc(p_sv), rs_hp = make_rsrc(p_hp), rs_do = make_rsrc(p_do ? p_do : p_hp);
+    const unsigned short* __restrict__ p_hp16 = BF ? J.hp16 : nullptr;      // h_prev as the forward's bf16 team kernel wrote it
+    const __amdgpu_buffer_rsrc_t rs_hp16 = make_rsrc(reinterpret_cast<const float*>(p_hp16 ? p_hp16 : reinterpret_cast<const unsigned short*>(p_hp)));
     const __amdgpu_buffer_rsrc_t rs_dgi = make_rsrc(p_dgi), rs_dghw = make_rsrc(p_dghw);
     const __amdgpu_buffer_rsrc_t rs_dgi16 = make_rsrc(reinterpret_cast<const float*>(p_dgi16 ? p_dgi16 : reinterpret_cast<unsigned short*>(p_dgi)));
     const __amdgpu_buffer_rsrc_t rs_dgh16 = make_rsrc(reinterpret_cast<const float*>(p_dgh16 ? p_dgh16 : reinterpret_cast<unsigned short*>(p_dghw)));
@@ -1625,7 +1638,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 sv = make_float4(__uint_as_float(s2.x << 16), __uint_as_float(s2.x & 0xffff0000u), __uint_as_float(s2.y << 16), __uint_as_float(s2.y & 0xffff0000u));
             } else
             sv = bload4(rs_sv, ((rix * HT + ht) * 64 + gn_l * 4) * 4u);
-            s_hp = bload1(rs_hp, (rix * D + j_l) * 4u);
+            if (BF && p_hp16) s_hp = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_hp16, (int)((rix * D + j_l) * 2u), 0, 0) << 16);
+            else s_hp = bload1(rs_hp, (rix * D + j_l) * 4u);
             s_do = p_do ? bload1(rs_do, (rix * (unsigned)ldh + j_l) * 4u) : 0.f;
         }
         // dH_{p+1} u_{p+1} of this (row, unit): written by this same thread one step ago
@@ -2089,6 +2103,7 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     int T = 0, C = 0;
     const bool team = forward_team(a, persistent, &T, &C);
     if (a.sv16 && !(team && a.bf16)) return hipErrorInvalidValue;      // 16-bit saved gates: the bf16 team kernels only
+    for (int i = 0; i < a.njobs; ++i) if ((a.job[i].hs16 || a.job[i].hp16) && !(team && a.bf16)) return hipErrorInvalidValue;
     for (int i = 0; i < a.njobs; ++i) if (a.job[i].gi_rows && !team) return hipErrorInvalidValue;      // only the team kernels index gi through gi_rows
     if (persistent && a.p_end - a.p_begin > 1) {
         // D = 512: independent 16-row teams sharing one LDS-resident weight slice per CU, the row blocks of a workgroup
@@ -2143,6 +2158,7 @@ bool gru_backward_uses_team(const GruArgs& a, bool persistent)
 hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
 {
     if (a.sv16 && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
+    for (int i = 0; i < a.njobs; ++i) if (a.job[i].hp16 && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
     for (int i = 0; i < a.njobs; ++i)      // 16-bit gate gradients are written by the bf16 team kernels only
         if ((a.job[i].dgi16 || a.job[i].dgh16) && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
 

@@ -67,6 +67,9 @@ struct GruJob {
     float* sv;            // saved r,u,n,hn: (S,B,HT,16,4) or nullptr
     float* hp;            // saved h_prev (S,B,D) or nullptr
     int reverse;          // 1: time index map of tf.reverse_sequence (needs lens)
+    // optional, bf16 team kernels only: the row-major h (indexed like hs, ldh) / h_prev (S,B,D) copies as bf16 INSTEAD of fp32
+    unsigned short* hs16;
+    unsigned short* hp16; //   (the backward reads h_prev from here when given)
     // backward only
     const float* dh_out;  // grad wrt hs (same indexing as hs: ldh) or nullptr
     float* dgi;           // (S,B,ldg) G16 columns (+ job offset)
@@ -164,6 +167,8 @@ hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32
 hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D);
 // h[b,:] = hs[(len_b-1)*B + b, :]  (model.py:135)
 hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W);
+// the same from a bf16 source: h[b,:] = float(hs16[(len_b-1)*B + b, :])
+hipError_t pick_last16(hipStream_t st, float* h, const unsigned short* hs16, const int32_t* lens, int B, int W);
 // dhs[(len_b-1)*B+b,:] += d[b,:]
 hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W);
 // dhs = 0 everywhere except dhs[(len_b-1)*B+b,:] = dh[b,:]

@@ -53,6 +53,7 @@ struct avae_ctx {
     int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
+    int bf16_act = 1;     // compute_dtype 1: h / h_prev row-major copies written as bf16 by the forward team kernels (the GEMM operands as they stand)
     int bf16_sv = 1;      // compute_dtype 1: saved gates as bf16 where a layer's forward and backward both run the team kernels
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
@@ -136,6 +137,8 @@ struct Ws {
     // backward
     float *dho, *dhc, *dhd[2], *dgi_d, *dgh_d, *dh0, *carry, *dh0sum, *dz, *dmu, *dlv, *dhpick;
     float *dhs[2], *dgi_e, *dgh_e, *demb_src, *demb_tgt;
+    std::vector<unsigned short*> e_hs16, d_hd16, e_hp16[2], d_hp16;      // bf16 mode: h / h_prev as the forward team kernels write them (bf16_act)
+    std::vector<char> act_e, act_d, acth_e, acth_d;                       // per layer: hs16 / hp16 in use this call
     std::vector<unsigned short*> x16_e, x16_d;                 // bf16 mode: the layer inputs as the forward GEMMs converted them (row-major: the backward's TN operand)
     const unsigned short* x16_kept_e(int i) const { return x16_valid ? x16_e[i] : nullptr; }
     const unsigned short* x16_kept_d(int i) const { return x16_valid ? x16_d[i] : nullptr; }
@@ -185,6 +188,14 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.e_gi.resize(L); w.e_hs.resize(L);
     for (int d = 0; d < 2; ++d) { w.e_sv[d].resize(L); w.e_hp[d].resize(L); }
     w.d_gi.resize(L); w.d_hd.resize(L); w.d_sv.resize(L); w.d_hp.resize(L);
+    w.e_hs16.assign(L, nullptr); w.d_hd16.assign(L, nullptr); w.e_hp16[0].assign(L, nullptr); w.e_hp16[1].assign(L, nullptr); w.d_hp16.assign(L, nullptr);
+    w.act_e.assign(L, 0); w.act_d.assign(L, 0); w.acth_e.assign(L, 0); w.acth_d.assign(L, 0);
+    if (train && h->cfg.compute_dtype == 1 && h->bf16_act && h->bf16_tn && D % 8 == 0)
+        for (int i = 0; i < L; ++i) {
+            w.e_hs16[i] = b.take<unsigned short>(rs * 2 * D); w.e_hp16[0][i] = b.take<unsigned short>(rs * D); w.e_hp16[1][i] = b.take<unsigned short>(rs * D);
+            if (i < L - 1) w.d_hd16[i] = b.take<unsigned short>(rt * D);
+            w.d_hp16[i] = b.take<unsigned short>(rt * D);
+        }
     w.x16_e.assign(L, nullptr); w.x16_d.assign(L, nullptr);
     w.x16_valid = train && h->cfg.compute_dtype == 1 && h->bf16_tn && !h->bf16_direct && D % 8 == 0;
     if (w.x16_valid)
@@ -312,9 +323,9 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
 // bf16 mode, A already bf16 and row-major ((rows, lda16), written by the producer -- the softmax gradient): as the A panel
 // itself (a_mc = false: k-contiguous) or transposed once from the 2-byte source (a_mc = true); B converted as usual.
 int gemm_bf16_pre(avae_ctx* h, const unsigned short* A16, int lda16, bool a_mc, const float* Bm, int ldb, bool b_nc, float* C, int ldc,
-                  int M, int N, int K, float alpha, int accumulate, int split_k, const int* dyn, int dyn_kind)
+                  int M, int N, int K, float alpha, int accumulate, int split_k, const int* dyn, int dyn_kind, const float* bias = nullptr)
 {
-    GemmArgs g{nullptr, Bm, C, nullptr, M, N, K, lda16, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, 0, nullptr, nullptr, nullptr, nullptr};
+    GemmArgs g{nullptr, Bm, C, bias, M, N, K, lda16, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, 0, nullptr, nullptr, nullptr, nullptr};
     Timed t(h, 0, 2.0 * M * N * K, dyn, dyn_kind == 1 ? M : (dyn_kind == 2 ? K : 0));
     const int Kp = (K + 7) & ~7;
     const unsigned short* Ap = A16; int lda_p = lda16;
@@ -513,15 +524,17 @@ int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
     for (int i = 0; i < n; ++i) w.ord_ok[which[i]] = true;
     return 0;
 }
-// bf16 mode: a layer whose forward AND backward launches both run the bf16 team kernels keeps its saved gates as bf16
-static void attach_sv16(avae_ctx* h, GruArgs& a, bool train)
+// bf16 mode: does a layer's forward AND backward launch both run the bf16 team kernels?  Then what passes between them (saved
+// gates, h_prev) and on to the GEMMs (h, gate gradients) can be 16-bit.
+static bool both_team_bf16(avae_ctx* h, const GruArgs& a, bool train)
 {
     int T = 0, cpj = 0, nrb = 0;
     GruArgs q = a; q.sv16 = 0; q.slens = nullptr; q.perm = nullptr;
-    for (int i = 0; i < q.njobs; ++i) { q.job[i].dgi16 = nullptr; q.job[i].dgh16 = nullptr; q.job[i].gi_rows = nullptr; }
+    for (int i = 0; i < q.njobs; ++i) { q.job[i].dgi16 = nullptr; q.job[i].dgh16 = nullptr; q.job[i].gi_rows = nullptr; q.job[i].hs16 = nullptr; q.job[i].hp16 = nullptr; }
     q.p_begin = 0; q.p_end = q.S;
-    a.sv16 = train && h->bf16_sv && a.bf16 && a.S > 1 && gru_team_shape(q, true, h->persistent != 0, &T, &cpj, &nrb) && gru_team_shape(q, false, h->persistent != 0, &T, &cpj, &nrb);
+    return train && a.bf16 && a.S > 1 && gru_team_shape(q, true, h->persistent != 0, &T, &cpj, &nrb) && gru_team_shape(q, false, h->persistent != 0, &T, &cpj, &nrb);
 }
+static void attach_sv16(avae_ctx* h, GruArgs& a, bool train) { a.sv16 = h->bf16_sv && both_team_bf16(h, a, train); }
 static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
 {
     int T = 0, cpj = 0, nrb = 0;
@@ -545,6 +558,8 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             AV_CHECK(id_groups_build(h->stream, w.src_tm, rs, V, w.grp_src, save));
             AV_CHECK(rows_gather(h->stream, w.emb_src, h->P + h->oE, id_groups_uid(w.grp_src, rs, V), cnt, std::min(V, rs), D));
             AV_TRY(gemm(h, false, false, w.emb_src, D, h->P + p.W, D, w.ew, 6 * D, std::min(V, rs), 6 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
+        } else if (i > 0 && w.act_e[i - 1]) {       // the layer below wrote its output as bf16: the A operand as it stands
+            AV_TRY(gemm_bf16_pre(h, w.e_hs16[i - 1], In, false, h->P + p.W, In, false, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, 0, 1, nullptr, 0, h->P + p.bW));
         } else {
         h->keep_a16 = save ? w.x16_e[i] : nullptr;
         AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, h->P + p.bW));
@@ -572,17 +587,25 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             j.reverse = d;
         }
         attach_sv16(h, a, save);
+        if (w.e_hs16[i] && tn16_ok(h, 3 * D, D) && both_team_bf16(h, a, save)) {      // h / h_prev as bf16 (a table-fed layer keeps h_prev fp32: its dR runs the fp32-operand path)
+            w.act_e[i] = 1; w.acth_e[i] = !table0;
+            for (int d = 0; d < a.njobs; ++d) { a.job[d].hs16 = w.e_hs16[i] + d * D; if (!table0) a.job[d].hp16 = w.e_hp16[d][i]; }
+        }
         attach_order(h, w, a, true, top1 ? 1 : 0);
         { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         if (top1) {
             // the backward direction at position len_b - 1: gi = W_b x[len_b - 1] + bW_b for B rows, then one cell step from h = 0
             const int64_t oWb = p.W + (int64_t)3 * D * In;
+            if (w.act_e[i - 1]) AV_CHECK(pick_last16(h->stream, w.xlast, w.e_hs16[i - 1], w.lens_src, B, In));
+            else
             AV_CHECK(pick_last(h->stream, w.xlast, x, w.lens_src, B, In));
             AV_TRY(gemm(h, false, false, w.xlast, In, h->P + oWb, In, w.gib, 3 * D, B, 3 * D, In, 1.f, h->P + p.bW + 3 * D));
         }
         x = w.e_hs[i]; In = 2 * D;
     }
+    if (w.act_e[L - 1]) AV_CHECK(pick_last16(h->stream, w.hpick, w.e_hs16[L - 1], w.lens_src, B, 2 * D));
+    else
     AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D));
     if (top_one_step(h))      // (the pick copied the never-written backward half of the top layer's rows: overwritten here)
         AV_CHECK(gru_first_step_fwd(h->stream, w.gib, h->P + h->enc[L - 1].bR + 3 * D, w.hpick + D, 2 * D, save ? w.svb : nullptr, B, D));
@@ -615,6 +638,8 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
             AV_CHECK(id_groups_build(h->stream, ids0, rt, V, w.grp_tgt, save));
             AV_CHECK(rows_gather(h->stream, w.emb_tgt, h->P + h->oE, id_groups_uid(w.grp_tgt, rt, V), cnt, std::min(V, rt), D));
             AV_TRY(gemm(h, false, false, w.emb_tgt, D, h->P + p.W, D, w.ew, 3 * D, std::min(V, rt), 3 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
+        } else if (i > 0 && w.act_d[i - 1]) {
+            AV_TRY(gemm_bf16_pre(h, w.d_hd16[i - 1], D, false, h->P + p.W, D, false, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, 0, 1, nullptr, 0, h->P + p.bW));
         } else {
         h->keep_a16 = save ? w.x16_d[i] : nullptr;
         AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
@@ -636,6 +661,10 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         j.hp = save ? w.d_hp[i] : nullptr;
         j.reverse = 0;
         attach_sv16(h, a, save);
+        if (w.d_hp16[i] && tn16_ok(h, 3 * D, D) && both_team_bf16(h, a, save)) {      // (the top layer keeps its fp32 output: the compaction and the out affine's gradient read it)
+            if (i < L - 1) { w.act_d[i] = 1; j.hs16 = w.d_hd16[i]; }
+            if (!table0) { w.acth_d[i] = 1; j.hp16 = w.d_hp16[i]; }
+        }
         if (T > 1) attach_order(h, w, a, true, 2);
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
@@ -754,6 +783,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         // (a table-fed layer keeps fp32: its gradients are summed by id first)
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) { j.dgi16 = w.dgi16_d; j.dgh16 = w.dgh16_d; }
+        if (w.acth_d[i]) j.hp16 = w.d_hp16[i];
         attach_sv16(h, a, true);
         attach_order(h, w, a, false, 2);
         hook_fence(h);
@@ -770,8 +800,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
         } else if (g16) {
             const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
-            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, w.x16_kept_d(i), x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr));
-            AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, nullptr, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, (i > 0 && w.act_d[i - 1]) ? w.d_hd16[i - 1] : w.x16_kept_d(i), x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, w.acth_d[i] ? w.d_hp16[i] : nullptr, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, nullptr));
             float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
             AV_TRY(gemm_bf16_pre(h, w.dgi16_d, 3 * D, false, P + p.W, D, true, dx, D, rt, D, 3 * D, 1.f, 0, 1, nullptr, 0));
         } else {
@@ -833,6 +863,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         }
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) for (int d = 0; d < a.njobs; ++d) { a.job[d].dgi16 = w.dgi16_e + d * 3 * D; a.job[d].dgh16 = w.dgh16_e + d * 3 * D; }
+        if (w.acth_e[i]) for (int d = 0; d < a.njobs; ++d) a.job[d].hp16 = w.e_hp16[d][i];
         attach_sv16(h, a, true);
         attach_order(h, w, a, false, top1 ? 1 : 0);
         hook_fence(h);
@@ -851,10 +882,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
                 fire_hook(h, 2 + 2 * L);
                 hook_flush(h);
             }
-            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, w.x16_kept_e(i), x, In, G + p.W, In, Gc, In, rs, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, (i > 0 && w.act_e[i - 1]) ? w.e_hs16[i - 1] : w.x16_kept_e(i), x, In, G + p.W, In, Gc, In, rs, 1.f, nullptr));
             if (top1) AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));
             for (int d = 0; d < a.njobs; ++d)
-                AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, nullptr));
+                AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, w.acth_e[i] ? w.e_hp16[d][i] : nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, nullptr));
             if (i > 0) AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, nullptr, 0));
             if (top1) {
                 AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
@@ -1128,6 +1159,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
     if (!strcmp(key, "bf16_sv")) { h->bf16_sv = value != 0; return 0; }
+    if (!strcmp(key, "bf16_act")) { h->bf16_act = value != 0; return 0; }
     if (!strcmp(key, "table_l1")) { h->table_l1 = value != 0; return 0; }
     if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
     if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }

@@ -554,6 +554,22 @@ hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* l
     hipLaunchKernelGGL(pick_last_kernel, dim3(B), dim3(256), 0, st, h, hs, lens, B, W);
     return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void pick_last16_kernel(float* __restrict__ h, const unsigned short* __restrict__ hs, const int32_t* __restrict__ lens, int B, int W)
+{
+    const int b = blockIdx.x;
+    const int t = max(lens[b] - 1, 0);
+    const uint2* s = reinterpret_cast<const uint2*>(hs + ((size_t)t * B + b) * W);      // four bf16 per access
+    float4* d = reinterpret_cast<float4*>(h + (size_t)b * W);
+    for (int c = threadIdx.x; c < W / 4; c += blockDim.x) {
+        const uint2 v = s[c];
+        d[c] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+}
+hipError_t pick_last16(hipStream_t st, float* h, const unsigned short* hs16, const int32_t* lens, int B, int W)
+{
+    hipLaunchKernelGGL(pick_last16_kernel, dim3(B), dim3(256), 0, st, h, hs16, lens, B, W);
+    return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void pick_last_add_kernel(float* __restrict__ dhs, const float* __restrict__ d,
                                                             const int32_t* __restrict__ lens, int B, int W)
 {
