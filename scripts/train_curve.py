@@ -19,13 +19,22 @@ def batch(seed):
     x[:, 0] = r.integers(3, V, B)
     for t in range(1, S):
         x[:, t] = succ[x[:, t - 1], r.choice(8, B, p=p)]
+    if os.environ.get('RAGGED'):                  # LogNormal lengths, eos padded (SURVEY 8d's RAGGED set): exercises the padding skip
+        lens = np.clip(np.rint(r.lognormal(np.log(24.0), 0.5, B)), 2, S).astype(int)
+        for b, n in enumerate(lens):
+            x[b, n:] = 1
     return x
 
 
 # MODES=round2: the default path (layers fed by embedding rows project the present ids) against the per-token
 # projection (table_l1 = 0) and the bf16-operand mode, same seeds
-ROUND2 = os.environ.get('MODES') == 'round2'
-RUNS = (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0}), ('f32s', 'bf16', {})) if ROUND2 else (('f32', 'f32', {}), ('f32 again', 'f32', {}), ('f32s', 'f32s', {}))
+# MODES=round3: the default path against the reference's graph executed as written (table_l1 = 0, enc_top1 = 0: all steps of the top
+# encoder layer's backward direction, skip_pad = 0: every step of every row) and the bf16-operand mode (bf16 gate gradients, saved
+# gates, h / h_prev; transposing-load GEMMs), same seeds
+ROUND2 = os.environ.get('MODES') in ('round2', 'round3')
+RUNS = (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0}), ('f32s', 'bf16', {})) if os.environ.get('MODES') == 'round2' else \
+       (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0, 'enc_top1': 0, 'skip_pad': 0}), ('f32s', 'bf16', {})) if os.environ.get('MODES') == 'round3' else \
+       (('f32', 'f32', {}), ('f32 again', 'f32', {}), ('f32s', 'f32s', {}))
 curves = {}
 for tag, dt, opts in RUNS:
     m = VAE('train', seed=0, dtype=dt, dim_tgt=V, dim_emb=512, dim_rep=128, rnn_layers=3)
