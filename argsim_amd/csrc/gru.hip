@@ -320,16 +320,29 @@ __device__ __forceinline__ void load_frag_scalar(float* dst, const float* base, 
 // on with the placement-independent sc1 protocol; if all HT ids agree the group's per-step stores
 // may stay in that XCD's L2 (plain stores) instead of being written through to the memory side.
 // All members read the same HT words, so they all take the same decision.
-__device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, int ht, int HT, int* err, int force_slow)
+// first half of the rendezvous, for kernels that have work to do before they need the answer (the team kernels copy their
+// weight slice to LDS in between: ~6 us per launch during which the other workgroups' publications arrive)
+__device__ __forceinline__ void xcd_publish(unsigned* ctr2, unsigned* ids, int ht)
+{
+    if (threadIdx.x == 0) {
+        const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
+        __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ bool group_same_xcd(unsigned* ctr2, unsigned* ids, int ht, int HT, int* err, int force_slow, bool published = false)
 {
     __shared__ int s_fast;
     if (threadIdx.x < 64) {          // the first wave: lane 0 publishes and waits, then lane i reads id i (one round trip, not HT)
         const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
         bool ok = true;
         if (threadIdx.x == 0) {
+            if (!published) {
             __hip_atomic_store(ids + ht, my + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             SpinGuard sg;
             while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HT)
                 if (sg.expired(err)) { ok = false; break; }
@@ -865,6 +878,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int cid = tm.cid, ht = tm.ht;
     const GruJob& J = a.job[tm.jb];
     const int B = a.B;
+    xcd_publish(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht);      // (collected after the weights are in LDS)
 
     // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
     if constexpr (BF) {   // block (wk', gate, q2): lane (n, kh) holds the 8 bf16 R'[ht*48 + n*3 + gate][wk'*WK + 32 q2 + 8 kh + e], e = 0..7
@@ -907,7 +921,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const __amdgpu_buffer_rsrc_t rs_hs16 = make_rsrc(reinterpret_cast<const float*>(p_hs16 ? p_hs16 : reinterpret_cast<unsigned short*>(p_hsw)));
     const __amdgpu_buffer_rsrc_t rs_hp16 = make_rsrc(reinterpret_cast<const float*>(p_hp16 ? p_hp16 : reinterpret_cast<unsigned short*>(p_hsw)));
     auto to_bf16 = [](float v) -> unsigned short { return (unsigned short)(pack_bf16(v, 0.f) & 0xffffu); };
-    const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
+    const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow, true);   // has a __syncthreads
     float* tpart = part + team * (KS * 3 * 256);
     float* thps = hps + team * 256;
     unsigned* tsync = sync + team;
@@ -1469,6 +1483,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int cid = tm.cid, ht = tm.ht;
     const GruJob& J = a.job[tm.jb];
     const int B = a.B, S = a.S;
+    xcd_publish(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht);      // (collected after the weights are in LDS)
 
     // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
     // the exchanged operand is in gate-major order inside a producer's 48 columns (kx = tile*48 + gate*16 + unit, so
@@ -1494,7 +1509,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int j = ht * 16 + gn;
     unsigned long long tp0 = 0, tp1 = 0;
     if constexpr (DIAG) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tp0 = __builtin_amdgcn_s_memrealtime(); }
-    const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow);   // has a __syncthreads
+    const bool fast = group_same_xcd(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht, HT, a.err, a.force_slow, true);   // has a __syncthreads
     if constexpr (DIAG) {
         tp1 = __builtin_amdgcn_s_memrealtime();
         if (tt == 0 && a.stamps && ((a.ablate & 256) ? T == 2 : T == 4)) {
