@@ -504,7 +504,7 @@ static void gru_common(avae_ctx* h, const Ws& w, GruArgs& a, int njobs, int S, i
 int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
 {
     if (!h->skip_pad || !h->persistent || B % 16) return 0;
-    const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
+    const int D = h->cfg.dim_emb;
     RowOrder ord[3]; int n = 0, which[3];
     auto want = [&](int k, int njobs, int S, int ldg, int ldh, const int32_t* lens, int add) {
         GruArgs a{};
@@ -514,7 +514,7 @@ int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
         ord[n] = RowOrder{lens, add, Tm, cpj, w.ord_perm[k], w.ord_slens[k]};
         which[n++] = k; w.ord_T[k] = Tm; w.ord_cpj[k] = cpj;
     };
-    if (!top_one_step(h) || L >= 2) want(0, 2, Ss, 6 * D, 2 * D, w.lens_src, 0);
+    want(0, 2, Ss, 6 * D, 2 * D, w.lens_src, 0);          // (every layer but a one-step top layer carries both directions)
     if (top_one_step(h)) want(1, 1, Ss, 6 * D, 2 * D, w.lens_src, 0);
     if (with_dec) want(2, 1, T, 3 * D, D, w.lens_tgt, 1);
     if (!n) return 0;

@@ -140,9 +140,11 @@ def _check_against_fixture(name, dtype, tz, tl, tg, check_adam=False, **vae_kw):
 
 @pytest.mark.parametrize("dtype,tz,tl,tg", [('f32', 2e-5, 2e-5, 2e-4), ('bf16', 3e-2, 1e-2, 5e-2)])
 def test_row_block_pipelined_kernels_against_the_oracle_fixture(dtype, tz, tl, tg):
-    """B = 512 (S = 14, ragged, D 512, V 8192): every GRU launch of the default path is a PIPE team instantiation -- what
-    configs[2] (bf16) and configs[3] (fp32) run -- compared with the float64 oracle fixture ONLY: loss, mu, log sigma^2,
-    per-variable gradient norm and one fixed projection of every gradient."""
+    """B = 512 (S = 14, ragged, D 512, V 8192): the two-direction encoder launches and the decoder launches of the default path
+    are PIPE team instantiations (two row blocks per workgroup), the one-job top encoder layer the 4-team form -- what
+    configs[2] (bf16: 16-bit exchange, bf16 gate gradients / saved gates / h, transposing-load GEMMs) and configs[3] (fp32)
+    run -- compared with the float64 oracle fixture ONLY: loss, mu, log sigma^2, per-variable gradient norm and one fixed
+    projection of every gradient."""
     _check_against_fixture('prod512', dtype, tz, tl, tg)
 
 
