@@ -315,3 +315,45 @@ def test_bf16_nt_gemm_large_tile_form(M, N, K):
     err = float((Cm.double() - ref).abs().max())
     assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ default path vs the graph as written
+@pytest.mark.parametrize("D,V,R,L,B,S,dtype", [
+    (512, 8192, 128, 3, 64, 9, 'f32'),      # one 64-row block, short rows
+    (512, 8192, 128, 2, 128, 33, 'f32'),    # two layers: the one-step top layer sits right on the table-fed layer
+    (512, 1024, 64, 3, 192, 17, 'f32'),     # B = 192: 2-team blocks of 32 rows; tokens > vocabulary on both sides
+    (512, 8192, 128, 1, 64, 12, 'f32'),     # one layer: no one-step form
+    (512, 8192, 128, 3, 48, 20, 'f32'),     # B = 48: no team geometry (register-form kernels), nothing to skip
+    (64, 256, 32, 3, 40, 14, 'f32'),        # small width: register-form kernels throughout
+    (512, 8192, 128, 3, 256, 21, 'bf16'),   # bf16 storage paths at one row block per workgroup
+    (512, 8192, 128, 2, 512, 11, 'bf16'),   # bf16, pipelined row blocks, two layers
+])
+def test_default_path_equals_the_graph_as_written(D, V, R, L, B, S, dtype):
+    """Every exact elimination and storage choice of the default path switched off at once (table_l1, enc_top1, skip_pad; bf16
+    mode: bf16_tn, bf16_sv, bf16_act as well) must give the same z, losses and gradients on ragged batches, over the launch
+    geometries the library distinguishes.  fp32: z to rounding (another K-split tree where a launch changes form), gradients
+    to float-atomic order; bf16: to the mode's accuracy."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=3, dtype=dtype, dim_tgt=V, dim_emb=D, dim_rep=R, rnn_layers=L)
+    m.step = 20000
+    ids = synth.batch(B, S, V, ragged=True, seed=B + S)
+    ids[1, 1:] = 1
+    ids[0, :] = synth.batch(1, S, V, seed=1)[0]          # one full-length row
+    rng = np.random.default_rng(5)
+    keep = (rng.random((S, B)) < 0.7).astype(np.uint8)
+    eps = rng.standard_normal((B, R)).astype(np.float32)
+    opts = ['table_l1', 'enc_top1', 'skip_pad'] + (['bf16_tn', 'bf16_sv', 'bf16_act'] if dtype == 'bf16' else [])
+    out = {}
+    for on in (1, 0):
+        for k in opts:
+            m.set_option(k, on)
+        z = m.encode(ids)
+        m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+        out[on] = (z, m.grads.clone(), m.losses())
+    tz, tl, tg = (2e-6, 2e-6, 2e-5) if dtype == 'f32' else (2e-2, 5e-3, 3e-2)
+    assert np.isfinite(out[1][0]).all() and np.abs(out[1][0] - out[0][0]).max() <= tz
+    assert abs(out[1][2][2] - out[0][2][2]) <= tl * abs(out[0][2][2])
+    d = float((out[1][1] - out[0][1]).norm() / out[0][1].norm())
+    assert d <= tg, d
+    m.close()
