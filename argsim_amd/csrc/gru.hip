@@ -1903,7 +1903,7 @@ hipError_t gru_first_step_bwd(hipStream_t st, const float* dh, int ldd, const fl
 
 // ------------------------------------------------------------------------------ launchers
 constexpr int kGruSyncWords = 64 + 64 + 1536;   // (spare) | detection counters | XCD ids (njobs*G*HT)
-bool gru_dim_supported(int D) { return D == 16 || D == 64 || D == 256 || D == 512; }
+bool gru_dim_supported(int D) { return D == 16 || D == 32 || D == 64 || D == 128 || D == 256 || D == 512; }
 
 #ifdef AVAE_DIAG
 constexpr bool kDiagBuild = true;
@@ -1955,7 +1955,9 @@ static hipError_t launch(hipStream_t st, const GruArgs& a, int grid, bool need_r
 #endif
     switch (a.D / 16) {
         AVAE_GRU_CASE(1)
+        AVAE_GRU_CASE(2)
         AVAE_GRU_CASE(4)
+        AVAE_GRU_CASE(8)
         AVAE_GRU_CASE(16)
         AVAE_GRU_CASE(32)
         default: return hipErrorInvalidValue;

@@ -1041,7 +1041,7 @@ int avae_create(const avae_config* cfg, int device, avae_handle* out)
 {
     if (!cfg || !out) { g_create_err = "null argument"; return 1; }
     *out = nullptr;
-    if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 64, 256, 512 (the GRU kernels are instantiated for these widths only; the reference leaves dim_emb free, config.json uses 512)"; return 1; }
+    if (!gru_dim_supported(cfg->dim_emb)) { g_create_err = "dim_emb must be one of 16, 32, 64, 128, 256, 512 (the GRU kernels are instantiated for these widths only; the reference leaves dim_emb free, config.json uses 512)"; return 1; }
     if (cfg->compute_dtype < 0 || cfg->compute_dtype > 2) { g_create_err = "compute_dtype must be 0 (fp32 MFMA), 1 (bf16 GEMM operands) or 2 (fp32 via split bf16 MFMA)"; return 1; }
     if (cfg->dim_rep % 4 || cfg->dim_tgt % 4 || cfg->rnn_layers < 1 || cfg->rnn_layers > 8) { g_create_err = "dim_rep and dim_tgt must be multiples of 4 (16-byte rows); 1 <= rnn_layers <= 8"; return 1; }
     int ndev = 0;

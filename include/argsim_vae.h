@@ -34,7 +34,7 @@ typedef struct avae_ctx* avae_handle;
 /* model section of src/config.json:10-21 + vAe() keyword defaults (src/model.py:48-66) */
 typedef struct avae_config {
     int32_t dim_tgt;      /* vocab size V                      */
-    int32_t dim_emb;      /* model dim D  (16,64,256 or 512)   */
+    int32_t dim_emb;      /* model dim D (16,32,64,128,256,512) */
     int32_t dim_rep;      /* latent dim R (multiple of 4)      */
     int32_t rnn_layers;   /* L                                 */
     float   accelerate;   /* schedule speed, model.py:77       */

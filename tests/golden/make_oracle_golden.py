@@ -40,7 +40,7 @@ def probe(name, shape):
 # (BIG_CASES, round 3: PIPE kernels at B = 512, R = 1024 / 512 through backward, the bench batch itself -- minutes of
 #  float64 autograd each; only written when named on the command line or with --big)
 big = [n for n in BIG_CASES if n in sys.argv[1:] or '--big' in sys.argv[1:]]
-for name in ([n for n in sys.argv[1:] if n in PROD_CASES] or ([] if big else list(PROD_CASES))) + big:
+for name in (list(PROD_CASES) if len(sys.argv) == 1 else [n for n in sys.argv[1:] if n in PROD_CASES]) + big:
     cfg, P, ids, keep, eps = make_case(name)
     extra = big_extras(name) if name in BIG_CASES else {}
     outs, grads = vt.loss_and_grads(P, cfg, ids, ids, 20000, keep, eps, **extra)

@@ -13,6 +13,9 @@ CASES = {
     'hot':   (dict(dim_tgt=8, dim_emb=16, dim_rep=8, rnn_layers=1), 24, 12, None),
     # more tokens than vocabulary entries: the layers fed by embedding rows project the table and gather / scatter by id
     'tab':   (dict(dim_tgt=64, dim_emb=64, dim_rep=16, rnn_layers=2), 12, 10, [10, 3, 7, 10, 1, 5, 9, 2, 10, 6, 4, 8]),
+    # the other widths the register-form GRU kernels are instantiated for (dim_emb 32 and 128)
+    'd32':   (dict(dim_tgt=128, dim_emb=32, dim_rep=16, rnn_layers=2), 6, 9, [9, 1, 4, 9, 2, 7]),
+    'd128':  (dict(dim_tgt=384, dim_emb=128, dim_rep=48, rnn_layers=3), 10, 11, [11, 2, 6, 11, 1, 9, 4, 8, 3, 10]),
     # a vocabulary beyond the scatter's LDS histogram: the per-element atomic fallback
     'bigv':  (dict(dim_tgt=12800, dim_emb=16, dim_rep=8, rnn_layers=1), 4, 6, [6, 2, 4, 1]),
 }
