@@ -77,12 +77,12 @@ def cpu_baseline(steps=5, warmups=2):
                        "absent and CudnnGRU is GPU-only) on the full %d x %d FULL batch of the headline workload" % (steps, warmups, b, s))
 
 
-def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None):
+def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None, **model_kw):
     """one of the other BASELINE configurations on this GPU, a few steps, with its kernel-class split (HIP events)"""
     import torch
     from argsim_amd import synth
     from argsim_amd.model import VAE
-    m = VAE('train', device=torch.cuda.current_device(), seed=0, dtype=dtype, **CFG)
+    m = VAE('train', device=torch.cuda.current_device(), seed=0, dtype=dtype, **dict(CFG, **model_kw))
     m.step = 20000
     ids = torch.as_tensor(synth.batch(b, s, CFG['dim_tgt'], seed=0)).to(m.device)
     for i in range(warmup):
@@ -353,6 +353,7 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = {
                 "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 operands in the GEMMs and the GRU recurrence (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128, pmc='configs2'),
+                "configs[4]": side_config("BASELINE configs[4]: 1xMI355X fp32, latent_dim 512 with the beta / free-bits extension live (kl_beta 0.5, free_bits 0.02), seq_len 64, batch 256", 'f32', 256, 64, steps=10, dim_rep=512, kl_beta=0.5, free_bits=0.02),
                 "configs[3]/gpu": side_config("BASELINE configs[3] per-GPU load: fp32, batch 1024 (global 8192 over 8 GPUs), seq_len 64; the all-reduce is not part of it", 'f32', 1024, 64),
             }
         print(json.dumps(out))
