@@ -354,6 +354,7 @@ def main():
             out["configs"] = {
                 "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 operands in the GEMMs and the GRU recurrence (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128, pmc='configs2'),
                 "configs[4]": side_config("BASELINE configs[4]: 1xMI355X fp32, latent_dim 512 with the beta / free-bits extension live (kl_beta 0.5, free_bits 0.02), seq_len 64, batch 256", 'f32', 256, 64, steps=10, dim_rep=512, kl_beta=0.5, free_bits=0.02),
+                "reference_training_geometry": side_config("the reference's own training geometry (src/config.json: batch_train 100, max_len 512, dim_rep 1024), FULL 512-piece rows, fp32 -- context for BASELINE.md section 1 (paper: ~1.14 s / step on an unstated NVIDIA GPU), not a BASELINE config", 'f32', 100, 512, steps=3, dim_rep=1024),
                 "configs[3]/gpu": side_config("BASELINE configs[3] per-GPU load: fp32, batch 1024 (global 8192 over 8 GPUs), seq_len 64; the all-reduce is not part of it", 'f32', 1024, 64),
             }
         print(json.dumps(out))
