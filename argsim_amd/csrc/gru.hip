@@ -984,7 +984,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int p_stop = nst0;                                    // (= a.p_end without slens)
     int ge_cur = tm.slot * RB + team * 16 + gr;                 // batch row of this thread's gate row in the current item
     if (perm) ge_cur = perm[ge_cur];
-    if (a.slens && gate_thread) {
+    const int* const rowmap = a.rowmap;       // (pos * B + row) -> row of the COMPACT external arrays, -1 for a padding position (nullptr: padded layout)
+    if (a.slens && gate_thread && !rowmap) {
         // positions behind a row block's steps: zeros in the row-major outputs (the GEMMs over all rows read them)
         for (int r = 0; r < tm.nrb; ++r) {
             const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
@@ -1006,10 +1007,15 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;                               // slot (exchange index); ge_cur: the batch row (external arrays)
         const int gpos = pos_map(p, len_g, J.reverse);
-        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;      // (byte offsets below 2^32: team_geometry checks)
+        const unsigned prix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;     // (byte offsets below 2^32: team_geometry checks)
+        // compact layout: every external array but a table-fed layer's row index is addressed by the row's place among the REAL
+        // positions; a padding position of a row shorter than its team's longest takes part in the exchange only
+        const int crow = (rowmap && gate_thread) ? rowmap[prix] : (int)prix;
+        const bool real = crow >= 0;
+        const unsigned rix = (unsigned)crow;
         float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, h0_own = 0.f;
-        if (gate_thread) {
-            const unsigned grix = p_girows ? (unsigned)p_girows[rix] : rix;          // (table-fed layer: the row of the per-id projection)
+        if (gate_thread && real) {
+            const unsigned grix = p_girows ? (unsigned)p_girows[prix] : rix;         // (table-fed layer: the row of the per-id projection)
             const u32x3 g3 = __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)((grix * (unsigned)a.ldg + ht * 48 + gn * 3) * 4u), 0, 0);
             gi0 = __uint_as_float(g3.x); gi1 = __uint_as_float(g3.y); gi2 = __uint_as_float(g3.z);
             if constexpr (BF) { if (p == 0 && J.h0 != nullptr) h0_own = bload1(rs_h0, ((unsigned)ge_cur * D + j) * 4u); }
@@ -1154,6 +1160,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                 const unsigned xo = xch_index(gpos, grow, j, B, D) * 4u;      // exchanged store first
                 if (fast) bstore1(not_sentinel(hnew), rs_hs, xo); else bstore1_sc1(not_sentinel(hnew), rs_hs, xo);
             }
+            if (real) {
             if (BF && p_hs16) __builtin_amdgcn_raw_buffer_store_b16(to_bf16(hnew), rs_hs16, (int)((rix * (unsigned)a.ldh + j) * 2u), 0, 0);
             else bstore1(hnew, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);       // the row-major copy the GEMMs and the next layer read
             if (p_svw) {
@@ -1165,6 +1172,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             }
             if (BF && p_hp16) __builtin_amdgcn_raw_buffer_store_b16(to_bf16(hprev), rs_hp16, (int)((rix * D + j) * 2u), 0, 0);
             else if (p_hpw) bstore1(hprev, rs_hpw, (rix * D + j) * 4u);
+            }
         }
         len_a = len2; len_g = len2g; ge_cur = ge2;
         TSTAMP(3);
@@ -1602,7 +1610,9 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int len_p0 = j_rev ? p_lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
     int ge_cur = tm.slot * RB + team * 16 + gr;                 // batch row of this thread's gate row in the current item
     if (perm) ge_cur = perm[ge_cur];
-    if (a.slens && gate_thread) {
+    const int* const rowmap = a.rowmap;       // compact layout of the external arrays (see the forward); J.dgi_by_pos: dgi keeps the padded layout
+    const bool dgi_by_pos = rowmap != nullptr && J.dgi_by_pos != 0;
+    if (a.slens && gate_thread && (!rowmap || dgi_by_pos)) {
         // positions behind a row block's steps: zero gate gradients (the weight-gradient GEMMs sum over every row)
         for (int r = 0; r < tm.nrb; ++r) {
             const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
@@ -1611,10 +1621,10 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 if (BF && p_dgi16 != nullptr) {
                     if ((gn & 1) == 0) {
                         const u32x3 z3 = {0u, 0u, 0u};
-                        __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgh16, (int)(orow >> 1), 0, 0);
+                        if (!rowmap) __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgh16, (int)(orow >> 1), 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgi16, (int)(orow >> 1), 0, 0);
                     }
-                } else { bstore3(0.f, 0.f, 0.f, rs_dghw, orow); bstore3(0.f, 0.f, 0.f, rs_dgi, orow); }
+                } else { if (!rowmap) bstore3(0.f, 0.f, 0.f, rs_dghw, orow); bstore3(0.f, 0.f, 0.f, rs_dgi, orow); }
             }
         }
     }
@@ -1644,9 +1654,12 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         BSTAMP(7);
         // (1) exchange-independent loads of the gate phase
         const int gpos = pos_map(p < 0 ? 0 : p, len_g, j_rev);
-        const unsigned rix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;      // (byte offsets below 2^32: team_geometry checks)
+        const unsigned prix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;     // (byte offsets below 2^32: team_geometry checks)
+        const int crow = (rowmap && gate_thread && p >= 0) ? rowmap[prix] : (int)prix;
+        const bool real = crow >= 0;                              // (a padding position: zero inputs, zero gradients, exchange only)
+        const unsigned rix = (unsigned)crow;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
-        if (p >= 0 && gate_thread) {
+        if (p >= 0 && gate_thread && real) {
             if (BF && a.sv16) {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 s2 = __builtin_amdgcn_raw_buffer_load_b64(rs_sv, (int)(((rix * HT + ht) * 64 + gn_l * 4) * 2u), 0, 0);
@@ -1801,6 +1814,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 else { bstore1_sc1(x0, rs_dgh, o0); bstore1_sc1(x1, rs_dgh, o0 + 1024u); bstore1_sc1(x2, rs_dgh, o0 + 2048u); }
             }
             const unsigned orow = (rix * (unsigned)ldg + ht * 48 + gn_l * 3) * 4u;
+            const unsigned orow_i = dgi_by_pos ? (prix * (unsigned)ldg + ht * 48 + gn_l * 3) * 4u : orow;      // dgi's own row (padded layout kept for a table-fed layer)
             if (BF && p_dgi16 != nullptr) {
                 // 16-bit row-major copies: the even unit's lane takes its odd neighbour's three values (quad-permute DPP: lanes
                 // 0,2 read lanes 1,3) and stores the six bf16 of both units as one 12-byte access
@@ -1812,16 +1826,16 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                 if ((gn_l & 1) == 0) {
                     const u32x3 vh = {pack_bf16(dr, du), pack_bf16(dnr, o_r), pack_bf16(o_u, o_nr)};
                     const u32x3 vi = {pack_bf16(dr, du), pack_bf16(dn, o_r), pack_bf16(o_u, o_n)};
-                    __builtin_amdgcn_raw_buffer_store_b96(vh, rs_dgh16, (int)(orow >> 1), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow >> 1), 0, 0);
+                    if (real) __builtin_amdgcn_raw_buffer_store_b96(vh, rs_dgh16, (int)(orow >> 1), 0, 0);
+                    if (real || dgi_by_pos) __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow_i >> 1), 0, 0);
                 }
                 if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
                 else carry_reg = dH * u;
             } else {
-            bstore3(dr, du, dn * r_, rs_dghw, orow);                 // the row-major copy the weight-gradient GEMM reads
+            if (real) bstore3(dr, du, dn * r_, rs_dghw, orow);                 // the row-major copy the weight-gradient GEMM reads
             if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
             else carry_reg = dH * u;
-            bstore3(dr, du, dn, rs_dgi, orow);
+            if (real || dgi_by_pos) bstore3(dr, du, dn, rs_dgi, orow_i);
             }
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }

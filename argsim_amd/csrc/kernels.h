@@ -78,6 +78,7 @@ struct GruJob {
     unsigned short* dgh16; //   (gru_backward_uses_team tells whether the launch will honour them)
     float* dh0;           // (B,D) or nullptr
     float* carry;         // (B,D) scratch: dH_{p+1} * u_{p+1}
+    int dgi_by_pos;       // with GruArgs::rowmap: dgi / dgi16 keep the padded (pos * B + row) layout, zeros at padding (a table-fed layer: summed by token id)
     float* dbW;           // (3D) G16 += column sums of dgi (or nullptr)
     float* dbR;           // (3D) G16 += column sums of dgh (or nullptr)
 };
@@ -89,6 +90,10 @@ struct GruArgs {
     // both or neither.  The other kernel forms ignore them and run every step of every row.
     const int* slens;     // (B) by slot
     const int* perm;      // (B) slot -> batch row
+    // optional, team kernels only: COMPACT external arrays.  rowmap[pos * B + row] = the row of gi / hs / sv / hp / dh_out / dgi / dgh
+    // that position has among the real (non-padding) positions in time-major order, -1 for a padding position (nothing is read
+    // or written for it; it still takes part in the exchange).  gi_rows (a table-fed layer) stays indexed by pos * B + row.
+    const int* rowmap;
     int G;                // batch groups per job
     int rows_per_group;   // multiple of 16
     int p_begin, p_end;   // steps [p_begin, p_end) of this launch
@@ -160,17 +165,20 @@ inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 
 // (slot of sorted group g: ((g % cpj) + (g / cpj / T) * cpj) * T + (g / cpj) % T).  perm[slot] = batch row, slens[slot] =
 // its steps.  Up to three geometries in one launch.
 struct RowOrder { const int32_t* lens; int add, T, cpj; int32_t* perm; int32_t* slens; };
-hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S);
+hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S, int32_t* steps_sum = nullptr, int sum_rows = 0);      // steps_sum[0..1] <- sum of the first order's steps, sum_rows
 // dst[i,:] = src[idx[i],:] for i < *n_dev
 hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);
 // dst[r,:] = rank[r] >= 0 ? src[rank[r],:] : 0   for r < rows
 hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D);
 // h[b,:] = hs[(len_b-1)*B + b, :]  (model.py:135)
-hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W);
+hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W, const int32_t* map = nullptr);      // (map: compact rows, row_map)
 // the same from a bf16 source: h[b,:] = float(hs16[(len_b-1)*B + b, :])
-hipError_t pick_last16(hipStream_t st, float* h, const unsigned short* hs16, const int32_t* lens, int B, int W);
+hipError_t pick_last16(hipStream_t st, float* h, const unsigned short* hs16, const int32_t* lens, int B, int W, const int32_t* map = nullptr);
 // dhs[(len_b-1)*B+b,:] += d[b,:]
-hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W);
+hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W, const int32_t* map = nullptr);
+// compact row map of an id source (ops.hip "compact row map"): map (S*B), nact (S scratch), count [1]
+hipError_t row_map(hipStream_t st, const int32_t* lens, int add, int S, int B, int32_t* map, int32_t* nact, int32_t* count);
+hipError_t zero_rows_dyn(hipStream_t st, float* X, const int32_t* count, int rows_max, int W);      // X[r,:] = 0 for r < min(rows_max, *count)
 // dhs = 0 everywhere except dhs[(len_b-1)*B+b,:] = dh[b,:]
 hipError_t pick_last_bwd(hipStream_t st, float* dhs, const float* dh, const int32_t* lens, int S, int B, int W);
 

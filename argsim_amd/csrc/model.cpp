@@ -49,6 +49,8 @@ struct avae_ctx {
     int persistent = 1;
     bool first_step_checked = false;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int compact = 2;      // encoder activations stored over the REAL rows only (row_map / GruArgs::rowmap): padded rows of a ragged batch cost nothing in the
+                          // encoder's GEMMs.  0 off, 1 on, 2 auto: on where the share of real positions the previous calls reported is below 0.85 (fill_hint)
     int skip_pad = 1;     // team GRU kernels skip the steps behind a row block's longest row (rows sorted by length, ops.hip row_order); 0: every step of every row
     int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
@@ -83,6 +85,9 @@ struct avae_ctx {
     // (dyn / dyn_max: a GEMM whose M or K is a device-side count -- its FLOPs are scaled by count / static bound at collection)
     struct Stamp { hipEvent_t a, b; int cls; double flops; const int* dyn; int dyn_max; };
     std::vector<Stamp> stamps; size_t stamps_used = 0;
+    // fill hint: the real source positions of an earlier call, copied to pinned host memory without a synchronisation (whatever has
+    // arrived is read; it only ever decides the LAYOUT, never a value) and the padded positions of the call that issued the copy
+    int32_t* hint_dev = nullptr; volatile int32_t* hint_host = nullptr;
     const int32_t *cnt_src = nullptr, *cnt_tgt = nullptr;     // present-id counts of the last forward (table-fed layers), device
 };
 
@@ -151,6 +156,8 @@ struct Ws {
     // row orders of the padding-skipping team kernels (build_row_orders): 0 = encoder, both directions; 1 = encoder, one job
     // (top layer); 2 = decoder.  ord_ok: built for this call with geometry (ord_T, ord_cpj)
     int32_t *ord_perm[3], *ord_slens[3]; int ord_T[3], ord_cpj[3]; bool ord_ok[3];
+    // compact encoder layout (build_compact): map_src[(t, b)] = row among the real source positions or -1, nsrc = how many
+    int32_t *map_src, *nact_src, *nsrc; bool compact;
 };
 
 struct Bump {
@@ -220,6 +227,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.xbuf_floats = rows * D * (train ? 3 : 1);
         w.xbuf = b.take<float>(w.xbuf_floats);
     }
+    w.map_src = b.take<int32_t>(rs); w.nact_src = b.take<int32_t>(Ss + 1); w.nsrc = b.take<int32_t>(4); w.compact = false;
     for (int k = 0; k < 3; ++k) { w.ord_perm[k] = b.take<int32_t>(B); w.ord_slens[k] = b.take<int32_t>(B); w.ord_ok[k] = false; w.ord_T[k] = w.ord_cpj[k] = 0; }
     w.hpick = b.take<float>((size_t)B * 2 * D);
     w.xlast = b.take<float>((size_t)B * 2 * D); w.gib = b.take<float>((size_t)B * 3 * D); w.svb = b.take<float>((size_t)B * 4 * D);
@@ -518,9 +526,18 @@ int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
     if (top_one_step(h)) want(1, 1, Ss, 6 * D, 2 * D, w.lens_src, 0);
     if (with_dec) want(2, 1, T, 3 * D, D, w.lens_tgt, 1);
     if (!n) return 0;
-    hipError_t e = row_order(h->stream, ord, n, B, std::max(Ss, T));
+    const bool hint = which[0] == 0 && h->compact == 2;        // (order 0 sorts the source rows: its step sum = the real source positions)
+    if (hint && !h->hint_host) {
+        int32_t* hp = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&hp), 64, hipHostMallocDefault) == hipSuccess) { hp[0] = -1; hp[1] = 0; h->hint_host = hp; }
+    }
+    h->hint_dev = reinterpret_cast<int32_t*>(h->errw + 100);     // (spare words of the error block)
+    hipError_t e = row_order(h->stream, ord, n, B, std::max(Ss, T), hint ? h->hint_dev : nullptr, Ss * B);
     if (e == hipErrorInvalidValue) return 0;                 // (a batch beyond the kernel's LDS: no order, every step runs)
     AV_CHECK(e);
+    if (hint && h->hint_host) {
+        AV_CHECK(hipMemcpyAsync(const_cast<int32_t*>(h->hint_host), h->hint_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
     for (int i = 0; i < n; ++i) w.ord_ok[which[i]] = true;
     return 0;
 }
@@ -542,12 +559,41 @@ static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
     a.slens = w.ord_slens[k]; a.perm = w.ord_perm[k];
 }
 
+// Compact encoder layout of this call: possible where every encoder GRU launch runs the team kernels (they address the
+// external arrays through GruArgs::rowmap) and the first layer is table-fed (its per-token arrays keep the padded order).
+int build_compact(avae_ctx* h, Ws& w, int B, int Ss, bool train)
+{
+    w.compact = false;
+    if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B)) return 0;
+    if (h->compact == 2) {
+        // auto: the layout pays where a good share of the padded positions is padding; on FULL batches the static row counts shape
+        // the GEMM launches better (16.8 vs 17.3 ms at configs[1]).  The hint is an EARLIER call's count (no synchronisation).
+        const int32_t real = h->hint_host ? h->hint_host[0] : -1, rows = h->hint_host ? h->hint_host[1] : 0;
+        if (real < 0 || rows <= 0 || (double)real >= 0.85 * (double)rows) return 0;
+    }
+    const int D = h->cfg.dim_emb;
+    for (int njobs = 1; njobs <= 2; ++njobs) {
+        if (njobs == 1 && !top_one_step(h)) continue;
+        GruArgs q{};
+        gru_common(h, w, q, njobs, Ss, B, 6 * D, 2 * D, w.lens_src);
+        int T = 0, cpj = 0, nrb = 0;
+        if (!gru_team_shape(q, true, true, &T, &cpj, &nrb) || (train && !gru_team_shape(q, false, true, &T, &cpj, &nrb))) return 0;
+    }
+    AV_CHECK(row_map(h->stream, w.lens_src, 0, Ss, B, w.map_src, w.nact_src, w.nsrc));
+    w.compact = true;
+    return 0;
+}
+
 int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 {
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
     const int rs = Ss * B;
     const bool table = use_table(h, rs);
     h->cnt_src = table ? id_groups_count(w.grp_src, rs, V) : nullptr;
+    // compact layout (build_compact): every array between the GEMMs and the GRU launches holds the real rows only; the GEMMs over
+    // them take the device-side row count
+    const int32_t* const cdyn = w.compact ? w.nsrc : nullptr;
+    const int32_t* const cmap = w.compact ? w.map_src : nullptr;
     if (!table) AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.src_tm, w.emb_src, rs, D, V));
     const float* x = w.emb_src; int In = D;
     for (int i = 0; i < L; ++i) {
@@ -559,10 +605,10 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             AV_CHECK(rows_gather(h->stream, w.emb_src, h->P + h->oE, id_groups_uid(w.grp_src, rs, V), cnt, std::min(V, rs), D));
             AV_TRY(gemm(h, false, false, w.emb_src, D, h->P + p.W, D, w.ew, 6 * D, std::min(V, rs), 6 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
         } else if (i > 0 && w.act_e[i - 1]) {       // the layer below wrote its output as bf16: the A operand as it stands
-            AV_TRY(gemm_bf16_pre(h, w.e_hs16[i - 1], In, false, h->P + p.W, In, false, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, 0, 1, nullptr, 0, h->P + p.bW));
+            AV_TRY(gemm_bf16_pre(h, w.e_hs16[i - 1], In, false, h->P + p.W, In, false, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, 0, 1, cdyn, cdyn ? 1 : 0, h->P + p.bW));
         } else {
         h->keep_a16 = save ? w.x16_e[i] : nullptr;
-        AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, h->P + p.bW));
+        AV_TRY(gemm(h, false, false, x, In, h->P + p.W, In, w.e_gi[i], 6 * D, rs, top1 ? 3 * D : 6 * D, In, 1.f, h->P + p.bW, 0, 0, cdyn, cdyn ? 1 : 0));
         h->keep_a16 = nullptr;
         }
         GruArgs a{};
@@ -592,21 +638,22 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             for (int d = 0; d < a.njobs; ++d) { a.job[d].hs16 = w.e_hs16[i] + d * D; if (!table0) a.job[d].hp16 = w.e_hp16[d][i]; }
         }
         attach_order(h, w, a, true, top1 ? 1 : 0);
+        a.rowmap = cmap;
         { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         if (top1) {
             // the backward direction at position len_b - 1: gi = W_b x[len_b - 1] + bW_b for B rows, then one cell step from h = 0
             const int64_t oWb = p.W + (int64_t)3 * D * In;
-            if (w.act_e[i - 1]) AV_CHECK(pick_last16(h->stream, w.xlast, w.e_hs16[i - 1], w.lens_src, B, In));
+            if (w.act_e[i - 1]) AV_CHECK(pick_last16(h->stream, w.xlast, w.e_hs16[i - 1], w.lens_src, B, In, cmap));
             else
-            AV_CHECK(pick_last(h->stream, w.xlast, x, w.lens_src, B, In));
+            AV_CHECK(pick_last(h->stream, w.xlast, x, w.lens_src, B, In, cmap));
             AV_TRY(gemm(h, false, false, w.xlast, In, h->P + oWb, In, w.gib, 3 * D, B, 3 * D, In, 1.f, h->P + p.bW + 3 * D));
         }
         x = w.e_hs[i]; In = 2 * D;
     }
-    if (w.act_e[L - 1]) AV_CHECK(pick_last16(h->stream, w.hpick, w.e_hs16[L - 1], w.lens_src, B, 2 * D));
+    if (w.act_e[L - 1]) AV_CHECK(pick_last16(h->stream, w.hpick, w.e_hs16[L - 1], w.lens_src, B, 2 * D, cmap));
     else
-    AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D));
+    AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D, cmap));
     if (top_one_step(h))      // (the pick copied the never-written backward half of the top layer's rows: overwritten here)
         AV_CHECK(gru_first_step_fwd(h->stream, w.gib, h->P + h->enc[L - 1].bR + 3 * D, w.hpick + D, 2 * D, save ? w.svb : nullptr, B, D));
     return 0;
@@ -686,6 +733,7 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4; p.zero2 = h->acc;
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(build_row_orders(h, w, B, Ss, T, true));
+    AV_TRY(build_compact(h, w, B, Ss, train));
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
     AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
@@ -834,6 +882,12 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_TRY(gemm(h, false, false, w.dmu, R, P + h->oWmu, R, w.dhpick, 2 * D, B, 2 * D, R));
     AV_TRY(gemm(h, false, false, w.dlv, R, P + h->oWlv, R, w.dhpick, 2 * D, B, 2 * D, R, 1.f, nullptr, 1));
     fire_hook(h, 1 + L);
+    const int32_t* const cdyn = w.compact ? w.nsrc : nullptr;        // compact encoder layout (build_compact)
+    const int32_t* const cmap = w.compact ? w.map_src : nullptr;
+    if (w.compact) {
+        AV_CHECK(zero_rows_dyn(st, w.dhs[0], w.nsrc, rs, 2 * D));
+        AV_CHECK(pick_last_add(st, w.dhs[0], w.dhpick, w.lens_src, B, 2 * D, cmap));
+    } else
     AV_CHECK(pick_last_bwd(st, w.dhs[0], w.dhpick, w.lens_src, Ss, B, 2 * D));
 
     // encoder stack
@@ -866,6 +920,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         if (w.acth_e[i]) for (int d = 0; d < a.njobs; ++d) a.job[d].hp16 = w.e_hp16[d][i];
         attach_sv16(h, a, true);
         attach_order(h, w, a, false, top1 ? 1 : 0);
+        a.rowmap = cmap;
+        if (cmap && i == 0) for (int d = 0; d < a.njobs; ++d) a.job[d].dgi_by_pos = 1;      // (table-fed: its gate gradients are summed by token id)
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -882,14 +938,14 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
                 fire_hook(h, 2 + 2 * L);
                 hook_flush(h);
             }
-            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, (i > 0 && w.act_e[i - 1]) ? w.e_hs16[i - 1] : w.x16_kept_e(i), x, In, G + p.W, In, Gc, In, rs, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgi16_e, nullptr, 6 * D, (i > 0 && w.act_e[i - 1]) ? w.e_hs16[i - 1] : w.x16_kept_e(i), x, In, G + p.W, In, Gc, In, rs, 1.f, cdyn));
             if (top1) AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));
             for (int d = 0; d < a.njobs; ++d)
-                AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, w.acth_e[i] ? w.e_hp16[d][i] : nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, nullptr));
-            if (i > 0) AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, nullptr, 0));
+                AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, w.acth_e[i] ? w.e_hp16[d][i] : nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, cdyn));
+            if (i > 0) AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, cdyn, cdyn ? 1 : 0));
             if (top1) {
                 AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
-                AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In));
+                AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In, cmap));
             }
             cur ^= 1;
             fire_hook(h, 2 + L + (L - 1 - i));
@@ -919,20 +975,20 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             } else
             AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
         } else if (top1) {
-            AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 3 * D, In, rs));                  // forward direction's W
+            AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 3 * D, In, rs, 1.f, cdyn));       // forward direction's W
             AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));              // backward direction's: B rows
         } else
-        AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs));
-        if (top1) AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs));
+        AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs, 1.f, cdyn));
+        if (top1) AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, cdyn));
         else {   // dR of the two directions: same shape, one launch
             const Pair bwd{w.dgh_e + 3 * D, w.e_hp[1][i], G + p.R + (int64_t)3 * D * D, nullptr};
-            AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, nullptr, &bwd));
+            AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, cdyn, &bwd));
         }
         if (i > 0)
-        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, top1 ? 3 * D : 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
+        AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, top1 ? 3 * D : 6 * D, 1.f, nullptr, 0, 0, cdyn, cdyn ? 1 : 0, true));
         if (top1) {       // the backward direction's input gradient lands on the rows at len_b - 1
             AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
-            AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In));
+            AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In, cmap));
         }
         cur ^= 1;
         fire_hook(h, 2 + L + (L - 1 - i));
@@ -1072,6 +1128,7 @@ void avae_destroy(avae_handle h)
     if (h->ws) (void)hipFree(h->ws);
     if (h->losses) (void)hipFree(h->losses);
     if (h->errw) (void)hipFree(h->errw);
+    if (h->hint_host) (void)hipHostFree(const_cast<int32_t*>(h->hint_host));
     if (h->counters) (void)hipFree(h->counters);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->bfA) (void)hipFree(h->bfA);
@@ -1164,6 +1221,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "enc_top1")) { h->enc_top1 = value != 0; return 0; }
     if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }
     if (!strcmp(key, "skip_pad")) { h->skip_pad = value != 0; return 0; }
+    if (!strcmp(key, "compact")) { h->compact = value; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");
@@ -1356,6 +1414,7 @@ int avae_encode(avae_handle h, const int32_t* src, int32_t b, int32_t t, float* 
     // tgt is unused by the encoder; feed the first column of src as a 1-wide dummy target
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(build_row_orders(h, w, b, t, 2, false));
+    AV_TRY(build_compact(h, w, b, t, false));
     AV_TRY(run_encoder(h, w, b, t, false));
     AV_TRY(run_latent(h, w, b, false, 0, nullptr));
     const size_t n = (size_t)b * h->cfg.dim_rep * sizeof(float);

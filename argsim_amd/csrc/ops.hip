@@ -514,12 +514,18 @@ hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32
 // ---------------------------------------------------------------- final-state pick (tf.gather_nd, model.py:135)
 // ---------------------------------------------------------------- row order for the padding-skipping GRU kernels
 struct RowOrders { RowOrder o[3]; };
-__global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int B, int S)
+__global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int B, int S, int32_t* __restrict__ steps_sum, int sum_rows)
 {
     extern __shared__ int steps[];                       // B ints
     const RowOrder o = ro.o[blockIdx.x];
     for (int b = threadIdx.x; b < B; b += blockDim.x) steps[b] = min(max(o.lens[b] + o.add, 1), S);
     __syncthreads();
+    if (steps_sum && blockIdx.x == 0 && threadIdx.x < 64) {      // real positions of the first order's id source (the host's fill hint)
+        int v = 0;
+        for (int b = threadIdx.x; b < B; b += 64) v += steps[b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0) { steps_sum[0] = v; steps_sum[1] = sum_rows; }      // (real positions, padded positions)
+    }
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const int mine = steps[b];
         int rank = 0;                                     // rows with more steps, or as many and a smaller index: stable, descending
@@ -530,52 +536,119 @@ __global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int B, in
         o.slens[slot] = mine;
     }
 }
-hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S)
+hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S, int32_t* steps_sum, int sum_rows)
 {
     if (n <= 0) return hipSuccess;
     if (n > 3 || B % 16 || (size_t)B * 4 > 64 * 1024) return hipErrorInvalidValue;
     RowOrders ro{};
     for (int i = 0; i < n; ++i) ro.o[i] = orders[i];
-    hipLaunchKernelGGL(row_order_kernel, dim3(n), dim3(1024), (size_t)B * sizeof(int), st, ro, B, S);
+    hipLaunchKernelGGL(row_order_kernel, dim3(n), dim3(1024), (size_t)B * sizeof(int), st, ro, B, S, steps_sum, sum_rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- compact row map of an id source
+// map[t * B + b] = the place of position (t, b) among the real positions (t < lens[b] + add) in time-major order, -1 for
+// padding; count[0] = how many.  Every array between the encoder's GEMMs and GRU launches is then stored over the real rows
+// only (GruArgs::rowmap): the padded rows of a ragged batch cost nothing anywhere.
+__global__ __launch_bounds__(256) void row_map_local_kernel(const int32_t* __restrict__ lens, int add, int B, int32_t* __restrict__ map, int32_t* __restrict__ nact)
+{
+    __shared__ int scan[256];
+    __shared__ int base_s;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + tid;
+        const int act = (b < B && t < lens[b] + add) ? 1 : 0;
+        scan[tid] = act;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int base = base_s;
+        if (b < B) map[(size_t)t * B + b] = act ? base + scan[tid] - 1 : -1;
+        __syncthreads();
+        if (tid == 255) base_s = base + scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) nact[t] = base_s;
+}
+__global__ __launch_bounds__(256) void row_map_offset_kernel(int B, int S, int32_t* __restrict__ map, const int32_t* __restrict__ nact, int32_t* __restrict__ count)
+{
+    __shared__ int red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    int pre = 0;
+    for (int c = tid; c < t; c += 256) pre += nact[c];
+    pre = block_sum256(pre, red);
+    __shared__ int off_s;
+    if (tid == 0) off_s = pre;
+    __syncthreads();
+    const int off = off_s;
+    for (int b = tid; b < B; b += 256) { const int v = map[(size_t)t * B + b]; if (v >= 0) map[(size_t)t * B + b] = v + off; }
+    if (t == S - 1 && tid == 0) count[0] = off + nact[t];
+}
+hipError_t row_map(hipStream_t st, const int32_t* lens, int add, int S, int B, int32_t* map, int32_t* nact, int32_t* count)
+{
+    hipLaunchKernelGGL(row_map_local_kernel, dim3(S), dim3(256), 0, st, lens, add, B, map, nact);
+    hipLaunchKernelGGL(row_map_offset_kernel, dim3(S), dim3(256), 0, st, B, S, map, nact, count);
+    return hipGetLastError();
+}
+// X[r, :] = 0 for r < min(rows_max, *count)
+__global__ __launch_bounds__(256) void zero_rows_dyn_kernel(float4* __restrict__ X, const int32_t* __restrict__ count, int rows_max, int W4)
+{
+    const size_t n = (size_t)min(rows_max, *count) * W4, stride = (size_t)gridDim.x * blockDim.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) X[i] = z;
+}
+hipError_t zero_rows_dyn(hipStream_t st, float* X, const int32_t* count, int rows_max, int W)
+{
+    hipLaunchKernelGGL(zero_rows_dyn_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<float4*>(X), count, rows_max, W / 4);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void pick_last_kernel(float* __restrict__ h, const float* __restrict__ hs,
-                                                        const int32_t* __restrict__ lens, int B, int W)
+                                                        const int32_t* __restrict__ lens, int B, int W, const int32_t* __restrict__ map)
 {
     const int b = blockIdx.x;
     int t = max(lens[b] - 1, 0);
-    const float4* s = reinterpret_cast<const float4*>(hs + ((size_t)t * B + b) * W);
+    const size_t row = map ? (size_t)max(map[(size_t)t * B + b], 0) : (size_t)t * B + b;
+    const float4* s = reinterpret_cast<const float4*>(hs + row * W);
     float4* d = reinterpret_cast<float4*>(h + (size_t)b * W);
     for (int c = threadIdx.x; c < W / 4; c += blockDim.x) d[c] = s[c];
 }
-hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W)
+hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W, const int32_t* map)
 {
-    hipLaunchKernelGGL(pick_last_kernel, dim3(B), dim3(256), 0, st, h, hs, lens, B, W);
+    hipLaunchKernelGGL(pick_last_kernel, dim3(B), dim3(256), 0, st, h, hs, lens, B, W, map);
     return hipGetLastError();
 }
-__global__ __launch_bounds__(256) void pick_last16_kernel(float* __restrict__ h, const unsigned short* __restrict__ hs, const int32_t* __restrict__ lens, int B, int W)
+__global__ __launch_bounds__(256) void pick_last16_kernel(float* __restrict__ h, const unsigned short* __restrict__ hs, const int32_t* __restrict__ lens, int B, int W,
+                                                          const int32_t* __restrict__ map)
 {
     const int b = blockIdx.x;
     const int t = max(lens[b] - 1, 0);
-    const uint2* s = reinterpret_cast<const uint2*>(hs + ((size_t)t * B + b) * W);      // four bf16 per access
+    const size_t row = map ? (size_t)max(map[(size_t)t * B + b], 0) : (size_t)t * B + b;
+    const uint2* s = reinterpret_cast<const uint2*>(hs + row * W);      // four bf16 per access
     float4* d = reinterpret_cast<float4*>(h + (size_t)b * W);
     for (int c = threadIdx.x; c < W / 4; c += blockDim.x) {
         const uint2 v = s[c];
         d[c] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
     }
 }
-hipError_t pick_last16(hipStream_t st, float* h, const unsigned short* hs16, const int32_t* lens, int B, int W)
+hipError_t pick_last16(hipStream_t st, float* h, const unsigned short* hs16, const int32_t* lens, int B, int W, const int32_t* map)
 {
-    hipLaunchKernelGGL(pick_last16_kernel, dim3(B), dim3(256), 0, st, h, hs16, lens, B, W);
+    hipLaunchKernelGGL(pick_last16_kernel, dim3(B), dim3(256), 0, st, h, hs16, lens, B, W, map);
     return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void pick_last_add_kernel(float* __restrict__ dhs, const float* __restrict__ d,
-                                                            const int32_t* __restrict__ lens, int B, int W)
+                                                            const int32_t* __restrict__ lens, int B, int W, const int32_t* __restrict__ map)
 {
     const int b = blockIdx.x;
     const int t = max(lens[b] - 1, 0);
-    float4* dst = reinterpret_cast<float4*>(dhs + ((size_t)t * B + b) * W);
+    const size_t row = map ? (size_t)max(map[(size_t)t * B + b], 0) : (size_t)t * B + b;
+    float4* dst = reinterpret_cast<float4*>(dhs + row * W);
     const float4* s = reinterpret_cast<const float4*>(d + (size_t)b * W);
     for (int c = threadIdx.x; c < W / 4; c += blockDim.x) {
         float4 v = dst[c]; const float4 a = s[c];
@@ -583,9 +656,9 @@ __global__ __launch_bounds__(256) void pick_last_add_kernel(float* __restrict__ 
         dst[c] = v;
     }
 }
-hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W)
+hipError_t pick_last_add(hipStream_t st, float* dhs, const float* d, const int32_t* lens, int B, int W, const int32_t* map)
 {
-    hipLaunchKernelGGL(pick_last_add_kernel, dim3(B), dim3(256), 0, st, dhs, d, lens, B, W);
+    hipLaunchKernelGGL(pick_last_add_kernel, dim3(B), dim3(256), 0, st, dhs, d, lens, B, W, map);
     return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void pick_last_bwd_kernel(float* __restrict__ dhs, const float* __restrict__ dh,

@@ -271,6 +271,7 @@ def test_padding_skipped_in_the_team_kernels_changes_nothing(B, S, dtype):
     from argsim_amd import synth
     from argsim_amd.model import VAE
     m = VAE('train', seed=1, dtype=dtype, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.set_option('compact', 0)                       # (the padded layout in both runs: the compact one has a test of its own)
     m.step = 20000
     ids = synth.batch(B, S, 8192, ragged=True, seed=7)
     ids[3, 1:] = 1                                   # a one-token row
@@ -329,7 +330,7 @@ def test_bf16_nt_gemm_large_tile_form(M, N, K):
     (512, 8192, 128, 2, 512, 11, 'bf16'),   # bf16, pipelined row blocks, two layers
 ])
 def test_default_path_equals_the_graph_as_written(D, V, R, L, B, S, dtype):
-    """Every exact elimination and storage choice of the default path switched off at once (table_l1, enc_top1, skip_pad; bf16
+    """Every exact elimination and storage choice of the default path switched off at once (table_l1, enc_top1, skip_pad, compact; bf16
     mode: bf16_tn, bf16_sv, bf16_act as well) must give the same z, losses and gradients on ragged batches, over the launch
     geometries the library distinguishes.  fp32: z to rounding (another K-split tree where a launch changes form), gradients
     to float-atomic order; bf16: to the mode's accuracy."""
@@ -343,7 +344,7 @@ def test_default_path_equals_the_graph_as_written(D, V, R, L, B, S, dtype):
     rng = np.random.default_rng(5)
     keep = (rng.random((S, B)) < 0.7).astype(np.uint8)
     eps = rng.standard_normal((B, R)).astype(np.float32)
-    opts = ['table_l1', 'enc_top1', 'skip_pad'] + (['bf16_tn', 'bf16_sv', 'bf16_act'] if dtype == 'bf16' else [])
+    opts = ['table_l1', 'enc_top1', 'skip_pad', 'compact'] + (['bf16_tn', 'bf16_sv', 'bf16_act'] if dtype == 'bf16' else [])
     out = {}
     for on in (1, 0):
         for k in opts:
@@ -356,4 +357,38 @@ def test_default_path_equals_the_graph_as_written(D, V, R, L, B, S, dtype):
     assert abs(out[1][2][2] - out[0][2][2]) <= tl * abs(out[0][2][2])
     d = float((out[1][1] - out[0][1]).norm() / out[0][1].norm())
     assert d <= tg, d
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------ compact encoder layout
+@pytest.mark.parametrize("B,S,dtype", [(256, 64, 'f32'), (64, 40, 'f32'), (512, 24, 'f32'), (1024, 20, 'f32'), (256, 40, 'bf16'), (512, 24, 'bf16')])
+def test_compact_encoder_layout_changes_nothing(B, S, dtype):
+    """Option compact: every array between the encoder's GEMMs and GRU launches holds the REAL rows only (row_map: the place of
+    (t, b) among the positions t < len_b in time-major order; GruArgs::rowmap), the GEMMs over them take the device-side row
+    count, the pick reads through the map.  Same values as the padded layout: z and the per-token losses bit for bit in
+    fp32 (a GEMM row's products do not depend on which row of the operand it is), gradients to float-atomic order."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    m = VAE('train', seed=1, dtype=dtype, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    ids = synth.batch(B, S, 8192, ragged=True, seed=9)
+    ids[5, 1:] = 1
+    out = {}
+    for c in (1, 0):
+        m.set_option('compact', c)
+        z = m.encode(ids)
+        ev = m.eval(ids, ids)
+        m.forward_backward(ids, ids, seed=5)
+        out[c] = (z, ev, m.grads.clone(), m.losses())
+    if dtype == 'f32':
+        assert np.array_equal(out[1][0], out[0][0])
+        for x, y in zip(out[1][1], out[0][1]):
+            assert np.array_equal(x, y)
+        tol = 1e-5
+    else:
+        assert np.abs(out[1][0] - out[0][0]).max() <= 1e-2
+        tol = 3e-2
+    d = float((out[1][2] - out[0][2]).norm() / out[0][2].norm())
+    assert d < tol, d
+    assert all(np.isfinite(out[1][3]))
     m.close()
