@@ -167,9 +167,9 @@ inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 
 struct RowOrder { const int32_t* lens; int add, T, cpj; int32_t* perm; int32_t* slens; };
 hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S, int32_t* steps_sum = nullptr, int sum_rows = 0);      // steps_sum[0..1] <- sum of the first order's steps, sum_rows
 // dst[i,:] = src[idx[i],:] for i < *n_dev
-hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D);
+hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D, const int32_t* map = nullptr);
 // dst[r,:] = rank[r] >= 0 ? src[rank[r],:] : 0   for r < rows
-hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D);
+hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D, const int32_t* map = nullptr);
 // h[b,:] = hs[(len_b-1)*B + b, :]  (model.py:135)
 hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W, const int32_t* map = nullptr);      // (map: compact rows, row_map)
 // the same from a bf16 source: h[b,:] = float(hs16[(len_b-1)*B + b, :])

@@ -158,6 +158,8 @@ struct Ws {
     int32_t *ord_perm[3], *ord_slens[3]; int ord_T[3], ord_cpj[3]; bool ord_ok[3];
     // compact encoder layout (build_compact): map_src[(t, b)] = row among the real source positions or -1, nsrc = how many
     int32_t *map_src, *nact_src, *nsrc; bool compact;
+    // the decoder's: map_tgt[(t, b)] over the positions t <= (last non-eos target position of row b) + 1, ntgt = how many
+    int32_t *map_tgt, *nact_tgt, *ntgt; bool compact_d;
 };
 
 struct Bump {
@@ -228,6 +230,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.xbuf = b.take<float>(w.xbuf_floats);
     }
     w.map_src = b.take<int32_t>(rs); w.nact_src = b.take<int32_t>(Ss + 1); w.nsrc = b.take<int32_t>(4); w.compact = false;
+    w.map_tgt = b.take<int32_t>(rt); w.nact_tgt = b.take<int32_t>(T + 1); w.ntgt = b.take<int32_t>(4); w.compact_d = false;
     for (int k = 0; k < 3; ++k) { w.ord_perm[k] = b.take<int32_t>(B); w.ord_slens[k] = b.take<int32_t>(B); w.ord_ok[k] = false; w.ord_T[k] = w.ord_cpj[k] = 0; }
     w.hpick = b.take<float>((size_t)B * 2 * D);
     w.xlast = b.take<float>((size_t)B * 2 * D); w.gib = b.take<float>((size_t)B * 3 * D); w.svb = b.take<float>((size_t)B * 4 * D);
@@ -561,9 +564,9 @@ static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
 
 // Compact encoder layout of this call: possible where every encoder GRU launch runs the team kernels (they address the
 // external arrays through GruArgs::rowmap) and the first layer is table-fed (its per-token arrays keep the padded order).
-int build_compact(avae_ctx* h, Ws& w, int B, int Ss, bool train)
+int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
 {
-    w.compact = false;
+    w.compact = false; w.compact_d = false;
     if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B)) return 0;
     if (h->compact == 2) {
         // auto: the layout pays where a good share of the padded positions is padding; on FULL batches the static row counts shape
@@ -581,6 +584,14 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, bool train)
     }
     AV_CHECK(row_map(h->stream, w.lens_src, 0, Ss, B, w.map_src, w.nact_src, w.nsrc));
     w.compact = true;
+    // the decoder stack the same way (training / evaluation calls: T > 1): a row's steps end one behind its last non-eos target id
+    if (T < 2 || !use_table(h, T * B) || h->compact == 3) return 0;      // (3: the encoder alone, for measurements)
+    GruArgs q{};
+    gru_common(h, w, q, 1, T, B, 3 * D, D, nullptr);
+    int Tm = 0, cpj = 0, nrb = 0;
+    if (!gru_team_shape(q, true, true, &Tm, &cpj, &nrb) || (train && !gru_team_shape(q, false, true, &Tm, &cpj, &nrb))) return 0;
+    AV_CHECK(row_map(h->stream, w.lens_tgt, 1, T, B, w.map_tgt, w.nact_tgt, w.ntgt));
+    w.compact_d = true;
     return 0;
 }
 
@@ -671,8 +682,11 @@ int run_latent(avae_ctx* h, Ws& w, int B, bool train, uint64_t seed, const float
 }
 
 // decoder GRU stack over T steps from per-layer initial states (state stride: layer * B * D; 0 = shared h0)
-int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int64_t state_stride, bool save, const int32_t* ids0 = nullptr)
+int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int64_t state_stride, bool save, const int32_t* ids0 = nullptr, bool compact = false)
 {
+    // compact layout (build_compact): the arrays between the GEMMs and the GRU launches hold the real rows only
+    const int32_t* const cdyn = compact ? w.ntgt : nullptr;
+    const int32_t* const cmap = compact ? w.map_tgt : nullptr;
     const int D = h->cfg.dim_emb, L = h->cfg.rnn_layers;
     const int rt = T * B;
     const float* x = w.emb_tgt;
@@ -686,10 +700,10 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
             AV_CHECK(rows_gather(h->stream, w.emb_tgt, h->P + h->oE, id_groups_uid(w.grp_tgt, rt, V), cnt, std::min(V, rt), D));
             AV_TRY(gemm(h, false, false, w.emb_tgt, D, h->P + p.W, D, w.ew, 3 * D, std::min(V, rt), 3 * D, D, 1.f, h->P + p.bW, 0, 0, cnt, 1));
         } else if (i > 0 && w.act_d[i - 1]) {
-            AV_TRY(gemm_bf16_pre(h, w.d_hd16[i - 1], D, false, h->P + p.W, D, false, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, 0, 1, nullptr, 0, h->P + p.bW));
+            AV_TRY(gemm_bf16_pre(h, w.d_hd16[i - 1], D, false, h->P + p.W, D, false, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, 0, 1, cdyn, cdyn ? 1 : 0, h->P + p.bW));
         } else {
         h->keep_a16 = save ? w.x16_d[i] : nullptr;
-        AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW));
+        AV_TRY(gemm(h, false, false, x, D, h->P + p.W, D, w.d_gi[i], 3 * D, rt, 3 * D, D, 1.f, h->P + p.bW, 0, 0, cdyn, cdyn ? 1 : 0));
         h->keep_a16 = nullptr;
         }
         GruArgs a{};
@@ -713,6 +727,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
             if (!table0) { w.acth_d[i] = 1; j.hp16 = w.d_hp16[i]; }
         }
         if (T > 1) attach_order(h, w, a, true, 2);
+        a.rowmap = cmap;
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.d_hd[i];
@@ -733,16 +748,16 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4; p.zero2 = h->acc;
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(build_row_orders(h, w, B, Ss, T, true));
-    AV_TRY(build_compact(h, w, B, Ss, train));
+    AV_TRY(build_compact(h, w, B, Ss, T, train));
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
     AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
-    if (use_table(h, rt)) AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train, w.lead));
+    if (use_table(h, rt)) AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train, w.lead, w.compact_d));
     else {
         AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.lead, w.emb_tgt, rt, D, V));
         AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train));
     }
-    AV_CHECK(rows_gather(h->stream, w.hc, w.d_hd[L - 1], w.cidx, w.ntok, rt, D));
+    AV_CHECK(rows_gather(h->stream, w.hc, w.d_hd[L - 1], w.cidx, w.ntok, rt, D, w.compact_d ? w.map_tgt : nullptr));
     AV_TRY(gemm(h, false, true, w.hc, D, h->P + h->oKout, D, w.ho, D, rt, D, D, 1.f, h->P + h->oBout, 0, 0, w.ntok, 1));
     AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 0, w.ntok, 1));
     CeArgs c{};
@@ -812,7 +827,9 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
     AV_CHECK(colsum(st, w.dho, rt, D, D, G + h->oBout, w.ntok));
     AV_TRY(gemm(h, false, false, w.dho, D, P + h->oKout, D, w.dhc, D, rt, D, D, 1.f, nullptr, 0, 0, w.ntok, 1, true));
     fire_hook(h, 0);
-    AV_CHECK(rows_expand(st, w.dhd[0], w.dhc, w.rank, rt, D));
+    const int32_t* const ddyn = w.compact_d ? w.ntgt : nullptr;        // compact decoder layout (build_compact)
+    const int32_t* const dmap = w.compact_d ? w.map_tgt : nullptr;
+    AV_CHECK(rows_expand(st, w.dhd[0], w.dhc, w.rank, rt, D, dmap));
 
     // decoder GRU stack, top layer first
     int cur = 0;
@@ -834,6 +851,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         if (w.acth_d[i]) j.hp16 = w.d_hp16[i];
         attach_sv16(h, a, true);
         attach_order(h, w, a, false, 2);
+        a.rowmap = dmap;
+        if (dmap && i == 0) j.dgi_by_pos = 1;       // (table-fed: its gate gradients are summed by token id)
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -843,23 +862,23 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             const int32_t* cnt = id_groups_count(w.grp_tgt, rt, V); const int U = std::min(V, rt);
             AV_CHECK(rows_group_sum(st, w.dew, w.lead, w.dgi_d, rt, 3 * D, V, w.grp_tgt));
             AV_TRY(gemm_tn_grad(h, w.dew, 3 * D, w.emb_tgt, D, G + p.W, D, 3 * D, D, U, 1.f, cnt));
-            AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt));
+            AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, ddyn));
             AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, w.demb_tgt, D, U, D, 3 * D, 1.f, nullptr, 0, 0, cnt, 1));
             AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
         } else if (g16) {
             const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
-            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, (i > 0 && w.act_d[i - 1]) ? w.d_hd16[i - 1] : w.x16_kept_d(i), x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr));
-            AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, w.acth_d[i] ? w.d_hp16[i] : nullptr, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, nullptr));
+            AV_TRY(gemm_tn16(h, w.dgi16_d, nullptr, 3 * D, (i > 0 && w.act_d[i - 1]) ? w.d_hd16[i - 1] : w.x16_kept_d(i), x, D, G + p.W, D, 3 * D, D, rt, 1.f, ddyn));
+            AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, w.acth_d[i] ? w.d_hp16[i] : nullptr, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, ddyn));
             float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
-            AV_TRY(gemm_bf16_pre(h, w.dgi16_d, 3 * D, false, P + p.W, D, true, dx, D, rt, D, 3 * D, 1.f, 0, 1, nullptr, 0));
+            AV_TRY(gemm_bf16_pre(h, w.dgi16_d, 3 * D, false, P + p.W, D, true, dx, D, rt, D, 3 * D, 1.f, 0, 1, ddyn, ddyn ? 1 : 0));
         } else {
         const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
         {   // dW = dgi^T x and dR = dgh^T h_prev: same shape over the same rows, one launch
             const Pair dR{w.dgh_d, w.d_hp[i], G + p.R, nullptr};
-            AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt, 1.f, nullptr, &dR));
+            AV_TRY(gemm_tn_grad(h, w.dgi_d, 3 * D, x, D, G + p.W, D, 3 * D, D, rt, 1.f, ddyn, &dR));
         }
         float* dx = i == 0 ? w.demb_tgt : w.dhd[cur ^ 1];
-        AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
+        AV_TRY(gemm(h, false, true, w.dgi_d, 3 * D, P + p.W, D, dx, D, rt, D, 3 * D, 1.f, nullptr, 0, 0, ddyn, ddyn ? 1 : 0, true));
         }
         cur ^= 1;
         fire_hook(h, 1 + (L - 1 - i));
@@ -1414,7 +1433,7 @@ int avae_encode(avae_handle h, const int32_t* src, int32_t b, int32_t t, float* 
     // tgt is unused by the encoder; feed the first column of src as a 1-wide dummy target
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(build_row_orders(h, w, b, t, 2, false));
-    AV_TRY(build_compact(h, w, b, t, false));
+    AV_TRY(build_compact(h, w, b, t, 0, false));
     AV_TRY(run_encoder(h, w, b, t, false));
     AV_TRY(run_latent(h, w, b, false, 0, nullptr));
     const size_t n = (size_t)b * h->cfg.dim_rep * sizeof(float);

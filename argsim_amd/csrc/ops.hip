@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void prep_ids_kernel(PrepArgs p, int per, int 
     for (int b = gid >> 6; b < B; b += nthr >> 6) {
         int ls = 0, lt = 0;
         for (int s = lane; s < p.Ss; s += 64) ls += p.src[(size_t)b * p.Ss + s] != p.eos;
-        for (int s = lane; s < p.St; s += 64) lt += p.tgt[(size_t)b * p.St + s] != p.eos;
+        // (source: the reference's length = the COUNT of non-eos ids, model.py:84; target: the decoder mask is per position, so the
+        //  steps that can reach the loss end one behind the LAST non-eos id, wherever other eos ids sit)
+        for (int s = lane; s < p.St; s += 64) if (p.tgt[(size_t)b * p.St + s] != p.eos) lt = s + 1;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o); lt += __shfl_xor(lt, o); }
+        for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o); lt = max(lt, __shfl_xor(lt, o)); }
         if (lane == 0) { p.lens_src[b] = ls; p.lens_tgt[b] = lt; }
     }
     for (int i = gid; i < p.Ss * B; i += nthr) {
@@ -473,29 +475,32 @@ hipError_t rows_add_indexed(hipStream_t st, float* dst, const float* src, const 
 // ---------------------------------------------------------------- compaction (tf.boolean_mask, model.py:161)
 __global__ __launch_bounds__(256) void rows_gather_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                           const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev,
-                                                          int n_max, int D)
+                                                          int n_max, int D, const int32_t* __restrict__ map)
 {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int n = min(n_max, *n_dev);
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
-        const float4* s = reinterpret_cast<const float4*>(src + (size_t)idx[row] * D);
+        const int sr = map ? map[idx[row]] : idx[row];          // (map: src is stored over the real rows only, row_map)
+        const float4* s = reinterpret_cast<const float4*>(src + (size_t)sr * D);
         float4* d = reinterpret_cast<float4*>(dst + (size_t)row * D);
         for (int c = lane; c < D / 4; c += 64) d[c] = s[c];
     }
 }
-hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D)
+hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D, const int32_t* map)
 {
     if (n_max <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rows_gather_kernel, dim3(min((n_max + 3) / 4, 2048)), dim3(256), 0, st, dst, src, idx, n_dev, n_max, D);
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(min((n_max + 3) / 4, 2048)), dim3(256), 0, st, dst, src, idx, n_dev, n_max, D, map);
     return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void rows_expand_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                          const int32_t* __restrict__ rank, int rows, int D)
+                                                          const int32_t* __restrict__ rank, int rows, int D, const int32_t* __restrict__ map)
 {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
         int r = rank[row];
-        float4* d = reinterpret_cast<float4*>(dst + (size_t)row * D);
+        const int dr = map ? map[row] : row;                    // (map: dst is stored over the real rows only; padding has no row)
+        if (dr < 0) continue;
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)dr * D);
         if (r >= 0) {
             const float4* s = reinterpret_cast<const float4*>(src + (size_t)r * D);
             for (int c = lane; c < D / 4; c += 64) d[c] = s[c];
@@ -504,10 +509,10 @@ __global__ __launch_bounds__(256) void rows_expand_kernel(float* __restrict__ ds
         }
     }
 }
-hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D)
+hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32_t* rank, int rows, int D, const int32_t* map)
 {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rows_expand_kernel, dim3(min((rows + 3) / 4, 2048)), dim3(256), 0, st, dst, src, rank, rows, D);
+    hipLaunchKernelGGL(rows_expand_kernel, dim3(min((rows + 3) / 4, 2048)), dim3(256), 0, st, dst, src, rank, rows, D, map);
     return hipGetLastError();
 }
 

@@ -95,6 +95,36 @@ def test_eval_outputs(name):
     assert abs(lk - o['loss_kld']) <= 2e-5 * abs(o['loss_kld']) + 1e-7
 
 
+@pytest.mark.parametrize("name", ['mid', 'tab'])
+def test_eos_in_the_middle_of_a_row(name):
+    """source != target and an eos id in the MIDDLE of a row, real ids behind it: the source length is the COUNT of non-eos ids
+    (util_tf.py:54-57: a prefix of that many positions enters the encoder, eos ids included), the decoder mask is per position
+    (model.py:161: the step behind the eos is dropped from the loss, the steps behind it are not, and the recurrence runs
+    through) -- losses, per-sentence outputs and gradients against the live oracle."""
+    cfg, P, ids, keep, eps = make_case(name)
+    src, tgt = ids.copy(), ids.copy()
+    full = [b for b in range(ids.shape[0]) if (ids[b] != cfg['eos']).sum() >= 9]
+    src[full[0], 4] = cfg['eos']
+    tgt[full[1], 5] = cfg['eos']
+    tgt[full[1], 2] = cfg['eos']
+    step = 20000
+    m = _vae(cfg, P)
+    m.step = step
+    errt, lgen, lkld = m.eval(src, tgt)
+    o = vn.forward(P, cfg, src, tgt, 'valid')
+    assert np.array_equal(errt, o['errt_samp'])
+    assert np.abs(lgen - o['loss_gen_samp']).max() <= 1e-4
+    assert np.abs(lkld - o['loss_kld_samp']).max() <= 2e-5
+    m.forward_backward(src, tgt, keep_mask=keep, eps=eps)
+    lg, lk, lo = m.losses()
+    outs, grads = vt.loss_and_grads(P, cfg, src, tgt, step, keep, eps)
+    assert abs(lg - outs['loss_gen']) <= 2e-5 * abs(outs['loss_gen'])
+    assert abs(lk - outs['loss_kld']) <= 2e-5 * abs(outs['loss_kld'])
+    got = m.get_grads()
+    bad = {k: rel_l2(got[k], grads[k]) for k in grads if rel_l2(got[k], grads[k]) > 2e-4}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("persistent", [1, 0])
 @pytest.mark.parametrize("name", list(CASES))
 def test_gradients(name, persistent):
