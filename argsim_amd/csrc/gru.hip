@@ -816,7 +816,7 @@ __device__ __forceinline__ TeamMap team_map(const GruArgs& a, int rows_per_block
     m.cid = blockIdx.x % C; m.ht = blockIdx.x / C;
     m.cpj = C / a.njobs;
     m.jb = m.cid / m.cpj; m.slot = m.cid % m.cpj;
-    m.nrb = (a.B / rows_per_block) / m.cpj;
+    m.nrb = ((a.Bx > a.B ? a.Bx : a.B) / rows_per_block) / m.cpj;
     return m;
 }
 
@@ -853,7 +853,7 @@ __device__ __forceinline__ int team_steps(const int* slens, int row0, int lane)
 // reads its operand like any other step; h_t lands in slot pos + 1.  The state h itself stays fp32: every gate thread keeps
 // the h_{t-1} of its (row, unit) in a register (one per row block) instead of picking it out of the exchanged operand; the
 // gate math and everything saved stay fp32.
-template <bool DIAG, bool PIPE, int T, bool BF = false>
+template <bool DIAG, bool PIPE, int T, bool BF = false, bool CMP = false>      // CMP: compact external arrays / phantom rows (GruArgs::rowmap, Bx)
 __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
 {
     const int ab = DIAG ? a.ablate : 0;                     // timing experiments / stamps: diagnostic instantiation only
@@ -877,7 +877,8 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
     const GruJob& J = a.job[tm.jb];
-    const int B = a.B;
+    const int Bs = a.B;                           // rows per position of every external array (Bs < B: slots whose perm entry is >= Bs are phantom rows)
+    const int B = (CMP && a.Bx > Bs) ? a.Bx : Bs; // rows of the launch geometry: the exchange scratch and everything indexed by slot
     xcd_publish(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht);      // (collected after the weights are in LDS)
 
     // weights -> LDS in B-fragment order: block (wk', gate, q): lane (n, kh) holds R'[ht*48 + n*3 + gate][wk'*128 + 16q + 4kh ..+3]
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int* const perm = a.perm;                                  // slot -> batch row of every external array (nullptr: identity)
     auto a_offset = [&](int p, int row0, int len_a) -> unsigned {
         if constexpr (BF) return xch_lane_offset(p == 0 ? 0 : pos_map(p - 1, len_a, J.reverse) + 1, row0, wk * (WK / 8), n, kh, B, D / 2);
-        if (p == 0) return (unsigned)((size_t)(perm ? perm[row0 + n] : row0 + n) * D * 4) + (wk * WK + 4 * kh) * 4;      // (row-major h0: an external array)
+        if (p == 0) return (unsigned)((size_t)(CMP ? min(perm ? perm[row0 + n] : row0 + n, Bs - 1) : (perm ? perm[row0 + n] : row0 + n)) * D * 4) + (wk * WK + 4 * kh) * 4;      // (row-major h0: an external array; a phantom row reads the last real one's)
         return xch_lane_offset(pos_map(p - 1, len_a, J.reverse), row0, wk * (WK / 4), n, kh, B, D);
     };
     auto q_stride = [&](int p) -> unsigned { return (p == 0 && !BF) ? 64u : 1024u; };
@@ -984,13 +985,13 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     const int p_stop = nst0;                                    // (= a.p_end without slens)
     int ge_cur = tm.slot * RB + team * 16 + gr;                 // batch row of this thread's gate row in the current item
     if (perm) ge_cur = perm[ge_cur];
-    const int* const rowmap = a.rowmap;       // (pos * B + row) -> row of the COMPACT external arrays, -1 for a padding position (nullptr: padded layout)
+    const int* const rowmap = CMP ? a.rowmap : nullptr;       // (pos * B + row) -> row of the COMPACT external arrays, -1 for a padding position (nullptr: padded layout)
     if (a.slens && gate_thread && !rowmap) {
         // positions behind a row block's steps: zeros in the row-major outputs (the GEMMs over all rows read them)
         for (int r = 0; r < tm.nrb; ++r) {
             const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
             for (int p = nst_of(r); p < a.p_end; ++p) {
-                const unsigned rix = (unsigned)p * (unsigned)B + (unsigned)ge;
+                const unsigned rix = (unsigned)p * (unsigned)Bs + (unsigned)ge;
                 if (BF && p_hs16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rs_hs16, (int)((rix * (unsigned)a.ldh + j) * 2u), 0, 0);
                 else bstore1(0.f, rs_hsw, (rix * (unsigned)a.ldh + j) * 4u);
                 if (BF && p_hp16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rs_hp16, (int)((rix * D + j) * 2u), 0, 0);
@@ -1007,11 +1008,12 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
         // (1) exchange-independent loads of the gate phase
         const int grow = row0 + gr;                               // slot (exchange index); ge_cur: the batch row (external arrays)
         const int gpos = pos_map(p, len_g, J.reverse);
-        const unsigned prix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;     // (byte offsets below 2^32: team_geometry checks)
+        const unsigned prix = (unsigned)gpos * (unsigned)Bs + (unsigned)ge_cur;     // (byte offsets below 2^32: team_geometry checks)
         // compact layout: every external array but a table-fed layer's row index is addressed by the row's place among the REAL
-        // positions; a padding position of a row shorter than its team's longest takes part in the exchange only
-        const int crow = (rowmap && gate_thread) ? rowmap[prix] : (int)prix;
-        const bool real = crow >= 0;
+        // positions; a padding position of a row shorter than its team's longest -- and every position of a phantom row -- takes
+        // part in the exchange only
+        const int crow = (rowmap && gate_thread) ? (ge_cur < Bs ? rowmap[prix] : -1) : (int)prix;
+        const bool real = !CMP || crow >= 0;
         const unsigned rix = (unsigned)crow;
         float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, h0_own = 0.f;
         if (gate_thread && real) {
@@ -1461,7 +1463,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_kernel(GruArgs a)
 // probe of the register-form D = 512 path above, with a ring of NB 24-register pieces (128-register budget at 4 waves
 // per SIMD) whose first NB pieces are in flight before the MFMAs start.  A job with dh0 (decoder layers) gets the
 // tail item p = -1: dh0 = carry + dgh_0 R.  Teams synchronise through monotonic LDS counters, never s_barrier.
-template <int NB, bool PIPE, int T, bool DIAG = false, bool BF = false>   // PIPE: several row blocks per workgroup; T teams of 16 / T waves; BF: bf16 operands (see the forward)
+template <int NB, bool PIPE, int T, bool DIAG = false, bool BF = false, bool CMP = false>   // CMP: compact external arrays / phantom rows (GruArgs::rowmap, Bx); PIPE: several row blocks per workgroup; T teams of 16 / T waves; BF: bf16 operands (see the forward)
 __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
 {
     // diagnostic phase stamps (DIAG instantiation only): [0] top loads [1] probe + first pieces [2] operand stream + MFMAs
@@ -1490,7 +1492,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
     const GruJob& J = a.job[tm.jb];
-    const int B = a.B, S = a.S;
+    const int Bs = a.B, S = a.S;                           // Bs: rows per position of the external arrays
+    const int B = (CMP && a.Bx > Bs) ? a.Bx : Bs;          // rows of the launch geometry (exchange scratch, slots)
     xcd_publish(a.counters + 64 + cid, a.counters + 128 + cid * HT, ht);      // (collected after the weights are in LDS)
 
     // weights -> LDS: block (wq, ks4): lane (n, kh) holds w[4 ks4 + e] = R'[wq*384 + 16 ks4 + 4 kh + e][ht*16 + n], e = 0..3
@@ -1610,14 +1613,15 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     const int len_p0 = j_rev ? p_lens[tm.slot * RB + team * 16 + 15] : 0;      // the probe's row (last of the team's 16)
     int ge_cur = tm.slot * RB + team * 16 + gr;                 // batch row of this thread's gate row in the current item
     if (perm) ge_cur = perm[ge_cur];
-    const int* const rowmap = a.rowmap;       // compact layout of the external arrays (see the forward); J.dgi_by_pos: dgi keeps the padded layout
+    const int* const rowmap = CMP ? a.rowmap : nullptr;       // compact layout of the external arrays (see the forward); J.dgi_by_pos: dgi keeps the padded layout
     const bool dgi_by_pos = rowmap != nullptr && J.dgi_by_pos != 0;
     if (a.slens && gate_thread && (!rowmap || dgi_by_pos)) {
         // positions behind a row block's steps: zero gate gradients (the weight-gradient GEMMs sum over every row)
         for (int r = 0; r < tm.nrb; ++r) {
             const int gs = (tm.slot + r * tm.cpj) * RB + team * 16 + gr, ge = perm ? perm[gs] : gs;
+            if (CMP && ge >= Bs) continue;                         // (a phantom row: no external row)
             for (int p = nst_of(r); p < a.p_end; ++p) {
-                const unsigned orow = (((unsigned)p * (unsigned)B + (unsigned)ge) * (unsigned)ldg + ht * 48 + gn * 3) * 4u;
+                const unsigned orow = (((unsigned)p * (unsigned)Bs + (unsigned)ge) * (unsigned)ldg + ht * 48 + gn * 3) * 4u;
                 if (BF && p_dgi16 != nullptr) {
                     if ((gn & 1) == 0) {
                         const u32x3 z3 = {0u, 0u, 0u};
@@ -1654,9 +1658,10 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
         BSTAMP(7);
         // (1) exchange-independent loads of the gate phase
         const int gpos = pos_map(p < 0 ? 0 : p, len_g, j_rev);
-        const unsigned prix = (unsigned)gpos * (unsigned)B + (unsigned)ge_cur;     // (byte offsets below 2^32: team_geometry checks)
-        const int crow = (rowmap && gate_thread && p >= 0) ? rowmap[prix] : (int)prix;
-        const bool real = crow >= 0;                              // (a padding position: zero inputs, zero gradients, exchange only)
+        const unsigned prix = (unsigned)gpos * (unsigned)Bs + (unsigned)ge_cur;     // (byte offsets below 2^32: team_geometry checks)
+        const bool inb = !CMP || ge_cur < Bs;                     // (false: a phantom row of a launch geometry wider than the batch)
+        const int crow = (rowmap && gate_thread && p >= 0) ? (inb ? rowmap[prix] : -1) : (int)prix;
+        const bool real = !CMP || crow >= 0;                             // (a padding position: zero inputs, zero gradients, exchange only)
         const unsigned rix = (unsigned)crow;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f); float s_hp = 0.f, s_do = 0.f;
         if (p >= 0 && gate_thread && real) {
@@ -1791,7 +1796,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             float carried = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             if constexpr (PIPE) carried += s_carry;
             else if (have_next) carried += carry_reg;
-            if (p < 0) { p_dh0[(size_t)ge_cur * D + j_l] = carried; len_a = len2; len_g = len2g; ge_cur = ge2; continue; }
+            if (p < 0) { if (inb) p_dh0[(size_t)ge_cur * D + j_l] = carried; len_a = len2; len_g = len2g; ge_cur = ge2; continue; }
             const float dH = carried + s_do;
             const float r_ = sv.x, u = sv.y, nn = sv.z;
             const float dn = dH * (1.f - u) * (1.f - nn * nn);
@@ -1827,7 +1832,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                     const u32x3 vh = {pack_bf16(dr, du), pack_bf16(dnr, o_r), pack_bf16(o_u, o_nr)};
                     const u32x3 vi = {pack_bf16(dr, du), pack_bf16(dn, o_r), pack_bf16(o_u, o_n)};
                     if (real) __builtin_amdgcn_raw_buffer_store_b96(vh, rs_dgh16, (int)(orow >> 1), 0, 0);
-                    if (real || dgi_by_pos) __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow_i >> 1), 0, 0);
+                    if (real || (dgi_by_pos && inb)) __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow_i >> 1), 0, 0);
                 }
                 if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
                 else carry_reg = dH * u;
@@ -1835,7 +1840,7 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             if (real) bstore3(dr, du, dn * r_, rs_dghw, orow);                 // the row-major copy the weight-gradient GEMM reads
             if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
             else carry_reg = dH * u;
-            if (real || dgi_by_pos) bstore3(dr, du, dn, rs_dgi, orow_i);
+            if (real || (dgi_by_pos && inb)) bstore3(dr, du, dn, rs_dgi, orow_i);
             }
             sb_r += dr; sb_u += du; sb_n += dn; sb_nr += dn * r_;
         }
@@ -2002,7 +2007,7 @@ __global__ __launch_bounds__(256) void gru_prepare_kernel(unsigned* sync_words, 
 // to bf16 in the tiled order of xch16_index, and S sentinel-filled slots behind it
 struct GruH0 { const float* p[kMaxGruJobs]; };
 __global__ __launch_bounds__(256) void gru_prepare16_kernel(unsigned* sync_words, int nsync, uint4* buf, size_t n16, size_t chunks_per_job,
-                                                            size_t seed_chunks, GruH0 h0s, int D, const int* perm)
+                                                            size_t seed_chunks, GruH0 h0s, int D, const int* perm, int ext_rows)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2017,8 +2022,10 @@ __global__ __launch_bounds__(256) void gru_prepare16_kernel(unsigned* sync_words
             if (h0) {
                 const size_t rb = c / ((size_t)(D >> 3) * 16), rem = c - rb * ((size_t)(D >> 3) * 16);
                 const size_t k8 = rem >> 4, slot = rb * 16 + (rem & 15), row = perm ? (size_t)perm[slot] : slot;      // (h0 is an external array)
+                if (row < (size_t)ext_rows) {
                 const float4 a0 = *reinterpret_cast<const float4*>(h0 + row * D + k8 * 8), a1 = *reinterpret_cast<const float4*>(h0 + row * D + k8 * 8 + 4);
                 v = make_uint4(pack_bf16(a0.x, a0.y), pack_bf16(a0.z, a0.w), pack_bf16(a1.x, a1.y), pack_bf16(a1.z, a1.w));
+                }
             }
         }
         buf[i] = v;
@@ -2033,13 +2040,14 @@ static hipError_t fill_sentinel2d(hipStream_t st, float* base, size_t rows, size
 // by side (the two encoder directions) are covered by ONE linear fill
 static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd, bool team)
 {
-    const size_t rows = (size_t)a.S * a.B, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
+    const size_t Bg = team && a.Bx > a.B ? a.Bx : a.B;          // (team kernels: the launch geometry's rows)
+    const size_t rows = (size_t)a.S * Bg, width = fwd ? a.D : 3 * (size_t)a.D, ld = fwd ? a.ldh : a.ldg;
     if (team && fwd && a.bf16) {
         GruH0 h0s{};
         for (int i = 0; i < a.njobs; ++i) h0s.p[i] = a.job[i].h0;
-        const size_t chunks_per_job = ((size_t)a.S + 1) * a.B * a.D / 8;
+        const size_t chunks_per_job = ((size_t)a.S + 1) * Bg * a.D / 8;
         hipLaunchKernelGGL(gru_prepare16_kernel, dim3(2048), dim3(256), 0, st, a.counters, kGruSyncWords, reinterpret_cast<uint4*>(a.xbuf),
-                           (size_t)a.njobs * chunks_per_job, chunks_per_job, (size_t)a.B * a.D / 8, h0s, a.D, a.perm);
+                           (size_t)a.njobs * chunks_per_job, chunks_per_job, Bg * a.D / 8, h0s, a.D, a.perm, a.B);
         return hipGetLastError();
     }
     if (team) {       // team kernels exchange through the tiled scratch buffer: one linear fill over every job's part
@@ -2066,22 +2074,16 @@ static hipError_t prepare_exchange(hipStream_t st, const GruArgs& a, bool fwd, b
 // geometry of the LDS-weight team kernels: C <= 8 chain groups x 32 hidden tiles = at most one 1024-thread workgroup
 // per CU; a chain group = one job and every (C / njobs)-th block of 16 T rows of it.  T = 4 teams (64-row blocks) where
 // that fills the chip, else T = 2 (32-row blocks, K split over 8 waves).  Returns false where neither applies.
-static bool team_geometry(const GruArgs& a, bool fwd, int* T, int* C)
+// which (T, C) a job count and a row count give (the batch-dependent half of team_geometry)
+static bool team_rows(int njobs, int B, int* T, int* C)
 {
-    if (a.D != 512 || a.njobs > 2 || a.p_begin != 0) return false;
-    // the tiled exchange scratch: present, 16-byte aligned, large enough, addressable with 32-bit byte offsets per job
-    const size_t per_job = (size_t)a.S * a.B * a.D * (fwd ? 1 : 3);
-    if (!a.xbuf || (((uintptr_t)a.xbuf) & 15) || a.xbuf_floats < per_job * a.njobs || per_job * 4 >= (1ull << 32)) return false;
-    // (the gate phase addresses gi / hs / saved gates / dgi / dgh with 32-bit byte offsets as well)
-    const size_t widest = std::max<size_t>((size_t)std::max(a.ldg, a.ldh), (size_t)4 * a.D);
-    if ((size_t)a.S * a.B * widest * 4 >= (1ull << 32)) return false;
     for (int t = 4; t >= 2; t >>= 1) {
         const int rb = 16 * t;
-        if (a.B % rb) continue;
-        const int nrbj = a.B / rb, np = a.njobs * nrbj;
+        if (B % rb) continue;
+        const int nrbj = B / rb, np = njobs * nrbj;
         if (np < 8) continue;                       // would leave CUs idle: try smaller blocks
         if (np == 8) { *T = t; *C = 8; return true; }
-        const int cpj = 8 / a.njobs;
+        const int cpj = 8 / njobs;
         if (nrbj % cpj || nrbj / cpj > 4) continue;      // (at most four row blocks per workgroup: the backward keeps one carry register per block)
         *T = t; *C = 8;
         return true;
@@ -2090,23 +2092,44 @@ static bool team_geometry(const GruArgs& a, bool fwd, int* T, int* C)
     // njobs x blocks x 32 CUs -- the forms of the benchmark geometry (4 teams for the encoder's two directions, 2 teams for
     // a decoder layer), which is what lets the B = 64 oracle fixtures of tests/test_gpu_round2.py reach them.
     for (int i = 0; i < 2; ++i) {
-        const int t = (a.njobs == 2) == (i == 0) ? 4 : 2, rb = 16 * t;
-        if (a.B % rb == 0 && a.njobs * (a.B / rb) <= 8) { *T = t; *C = a.njobs * (a.B / rb); return true; }
+        const int t = (njobs == 2) == (i == 0) ? 4 : 2, rb = 16 * t;
+        if (B % rb == 0 && njobs * (B / rb) <= 8) { *T = t; *C = njobs * (B / rb); return true; }
     }
     return false;
+}
+// The smallest row count >= B the team kernels have a geometry for with one job AND with two (0: none within 64 rows): a
+// batch of any size runs them with that many slots, the slots beyond B holding phantom rows (GruArgs::Bx).
+int gru_team_batch(int B)
+{
+    int T = 0, C = 0;
+    for (int bx = (B + 15) / 16 * 16; bx <= B + 64; bx += 16)
+        if (team_rows(1, bx, &T, &C) && team_rows(2, bx, &T, &C)) return bx;
+    return 0;
+}
+static bool team_geometry(const GruArgs& a, bool fwd, int* T, int* C)
+{
+    if (a.D != 512 || a.njobs > 2 || a.p_begin != 0) return false;
+    const int Bg = a.Bx > a.B ? a.Bx : a.B;
+    // the tiled exchange scratch: present, 16-byte aligned, large enough, addressable with 32-bit byte offsets per job
+    const size_t per_job = (size_t)a.S * Bg * a.D * (fwd ? 1 : 3);
+    if (!a.xbuf || (((uintptr_t)a.xbuf) & 15) || a.xbuf_floats < per_job * a.njobs || per_job * 4 >= (1ull << 32)) return false;
+    // (the gate phase addresses gi / hs / saved gates / dgi / dgh with 32-bit byte offsets as well)
+    const size_t widest = std::max<size_t>((size_t)std::max(a.ldg, a.ldh), (size_t)4 * a.D);
+    if ((size_t)a.S * a.B * widest * 4 >= (1ull << 32)) return false;
+    return team_rows(a.njobs, Bg, T, C);
 }
 
 template <class K>
 static hipError_t launch_team(hipStream_t st, K kernel, const GruArgs& a, int lds_bytes, int C)
 {
-    static const void* attr_done[32]; static int nattr = 0;
+    static const void* attr_done[64]; static int nattr = 0;
     const void* kp = reinterpret_cast<const void*>(kernel);
     bool seen = false;
     for (int i = 0; i < nattr; ++i) seen |= attr_done[i] == kp;
     if (!seen) {
         hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
-        if (nattr < 32) attr_done[nattr++] = kp;
+        if (nattr < 64) attr_done[nattr++] = kp;
     }
     const int grid = C * 32;
     hipError_t e = resident(kernel, 1024, lds_bytes, grid);
@@ -2136,13 +2159,16 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
     if (a.sv16 && !(team && a.bf16)) return hipErrorInvalidValue;      // 16-bit saved gates: the bf16 team kernels only
     for (int i = 0; i < a.njobs; ++i) if ((a.job[i].hs16 || a.job[i].hp16) && !(team && a.bf16)) return hipErrorInvalidValue;
     for (int i = 0; i < a.njobs; ++i) if (a.job[i].gi_rows && !team) return hipErrorInvalidValue;      // only the team kernels index gi through gi_rows
+    if ((a.rowmap || a.Bx > a.B) && !team) return hipErrorInvalidValue;                                // ... and know the compact layout / phantom rows
+    if (a.Bx > a.B && (!a.slens || !a.perm || !a.rowmap)) return hipErrorInvalidValue;                 // (phantom rows exist through the row order and the row map only)
     if (persistent && a.p_end - a.p_begin > 1) {
         // D = 512: independent 16-row teams sharing one LDS-resident weight slice per CU, the row blocks of a workgroup
         // interleaved item by item (team_geometry picks 4 teams x 4 waves or 2 teams x 8 waves)
         e = prepare_exchange(st, a, true, team); if (e != hipSuccess) return e;
         if (team) {
             const int lds_bytes = (96 * 256 + 48 * 256 + 4 * 256) * 4 + 128;
-            const bool pipe = a.njobs * (a.B / (16 * T)) > C;      // several row blocks per workgroup
+            const bool pipe = a.njobs * ((a.Bx > a.B ? a.Bx : a.B) / (16 * T)) > C;      // several row blocks per workgroup
+            const bool cmp = a.rowmap != nullptr;                                          // the instantiation that knows the compact layout
 #ifdef AVAE_DIAG
             if (a.ablate) {
                 return pipe ? launch_team(st, gru_fwd_team_kernel<true, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<true, false, 4>, a, lds_bytes, C);
@@ -2150,11 +2176,11 @@ hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent)
 #endif
             {
                 if (a.bf16) {
-                    if (T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 4, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4, true>, a, lds_bytes, C);
-                    return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 2, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2, true>, a, lds_bytes, C);
+                    if (T == 4) return pipe ? (cmp ? launch_team(st, gru_fwd_team_kernel<false, true, 4, true, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, true, 4, true, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_fwd_team_kernel<false, false, 4, true, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4, true, false>, a, lds_bytes, C));
+                    return pipe ? (cmp ? launch_team(st, gru_fwd_team_kernel<false, true, 2, true, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, true, 2, true, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_fwd_team_kernel<false, false, 2, true, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2, true, false>, a, lds_bytes, C));
                 }
-                if (T == 4) return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 4>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4>, a, lds_bytes, C);
-                return pipe ? launch_team(st, gru_fwd_team_kernel<false, true, 2>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2>, a, lds_bytes, C);
+                if (T == 4) return pipe ? (cmp ? launch_team(st, gru_fwd_team_kernel<false, true, 4, false, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, true, 4, false, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_fwd_team_kernel<false, false, 4, false, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 4, false, false>, a, lds_bytes, C));
+                return pipe ? (cmp ? launch_team(st, gru_fwd_team_kernel<false, true, 2, false, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, true, 2, false, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_fwd_team_kernel<false, false, 2, false, true>, a, lds_bytes, C) : launch_team(st, gru_fwd_team_kernel<false, false, 2, false, false>, a, lds_bytes, C));
             }
         }
         // benchmark geometry (D = 512, two full 16-row chunks per workgroup): software-pipelined kernel
@@ -2177,7 +2203,7 @@ bool gru_team_shape(const GruArgs& a, bool fwd, bool persistent, int* T, int* cp
     int C = 0;
     if (fwd ? !forward_team(a, persistent, T, &C) : !(persistent && team_geometry(a, false, T, &C) && !a.ablate && a.item_pipeline == 2)) return false;
     *cpj = C / a.njobs;
-    *nrb = (a.B / (16 * *T)) / *cpj;
+    *nrb = ((a.Bx > a.B ? a.Bx : a.B) / (16 * *T)) / *cpj;
     return *cpj >= 1 && *nrb >= 1 && *nrb <= 4;
 }
 bool gru_backward_uses_team(const GruArgs& a, bool persistent)
@@ -2194,13 +2220,16 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
         if ((a.job[i].dgi16 || a.job[i].dgh16) && !(a.bf16 && gru_backward_uses_team(a, persistent))) return hipErrorInvalidValue;
 
     int grid; hipError_t e = check(a, &grid); if (e != hipSuccess) return e;
+    if ((a.rowmap || a.Bx > a.B) && !gru_backward_uses_team(a, persistent)) return hipErrorInvalidValue;      // compact layout / phantom rows: team kernels only
+    if (a.Bx > a.B && (!a.slens || !a.perm || !a.rowmap)) return hipErrorInvalidValue;
     if (persistent) {
         int T = 0, C = 0;
         const bool team = team_geometry(a, false, &T, &C) && !(a.ablate & ~(16 | 128 | 256)) && a.item_pipeline == 2;
         e = prepare_exchange(st, a, false, team); if (e != hipSuccess) return e;
         if (team) {
             const int lds_bytes = (4 * 24 * 256 + 16 * 256 + 64) * 4 + 64;
-            const bool pipe = a.njobs * (a.B / (16 * T)) > C;
+            const bool pipe = a.njobs * ((a.Bx > a.B ? a.Bx : a.B) / (16 * T)) > C;
+            const bool cmp = a.rowmap != nullptr;
 #ifdef AVAE_DIAG
             if (a.ablate & 128) {
                 if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4, true>, a, lds_bytes, C);
@@ -2208,11 +2237,11 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent)
             }
 #endif
             if (a.bf16) {
-                if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4, false, true>, a, lds_bytes, C);
-                return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2, false, true>, a, lds_bytes, C);
+                if (T == 4) return pipe ? (cmp ? launch_team(st, gru_bwd_team_kernel<2, true, 4, false, true, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, true, 4, false, true, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_bwd_team_kernel<2, false, 4, false, true, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4, false, true, false>, a, lds_bytes, C));
+                return pipe ? (cmp ? launch_team(st, gru_bwd_team_kernel<2, true, 2, false, true, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, true, 2, false, true, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_bwd_team_kernel<2, false, 2, false, true, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2, false, true, false>, a, lds_bytes, C));
             }
-            if (T == 4) return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 4>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4>, a, lds_bytes, C);
-            return pipe ? launch_team(st, gru_bwd_team_kernel<2, true, 2>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2>, a, lds_bytes, C);
+            if (T == 4) return pipe ? (cmp ? launch_team(st, gru_bwd_team_kernel<2, true, 4, false, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, true, 4, false, false, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_bwd_team_kernel<2, false, 4, false, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 4, false, false, false>, a, lds_bytes, C));
+            return pipe ? (cmp ? launch_team(st, gru_bwd_team_kernel<2, true, 2, false, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, true, 2, false, false, false>, a, lds_bytes, C)) : (cmp ? launch_team(st, gru_bwd_team_kernel<2, false, 2, false, false, true>, a, lds_bytes, C) : launch_team(st, gru_bwd_team_kernel<2, false, 2, false, false, false>, a, lds_bytes, C));
         }
         return launch<false>(st, a, grid, true);
     }

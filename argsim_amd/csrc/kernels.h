@@ -94,6 +94,10 @@ struct GruArgs {
     // that position has among the real (non-padding) positions in time-major order, -1 for a padding position (nothing is read
     // or written for it; it still takes part in the exchange).  gi_rows (a table-fed layer) stays indexed by pos * B + row.
     const int* rowmap;
+    // optional, team kernels only, with slens + perm + rowmap: the launch geometry's batch, a multiple of the 16 T-row block above B.
+    // Slots hold Bx rows (slens / perm have Bx entries, the exchange scratch and the carry Bx rows); a slot whose perm entry is >= B is
+    // a PHANTOM row (slens 1): nothing external is read or written for it.  Every external array keeps B rows per position.  0: B.
+    int Bx;
     int G;                // batch groups per job
     int rows_per_group;   // multiple of 16
     int p_begin, p_end;   // steps [p_begin, p_end) of this launch
@@ -115,6 +119,7 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
 // geometry of the team kernels a launch of this shape would run: T teams of 16 rows per 16 T-row block, cpj chain groups
 // (workgroups) per job and hidden tile, nrb row blocks per workgroup; false: another kernel form runs (no slens / perm)
 bool gru_team_shape(const GruArgs& a, bool fwd, bool persistent, int* T, int* cpj, int* nrb);
+int gru_team_batch(int B);        // smallest row count >= B (within 64) the team kernels have a geometry for with one job and with two; 0: none
 bool gru_backward_uses_team(const GruArgs& a, bool persistent);     // true: the launch runs the LDS-weight team kernels (dgi16 / dgh16 honoured in bf16 mode)
 bool gru_dim_supported(int D);
 // one GRU step from a zero state for B rows (the top encoder layer's backward direction: gru.hip "one step from a zero
@@ -165,7 +170,7 @@ inline size_t embed_scatter_scratch_ints(size_t n, size_t V) { return 4 * V + 2 
 // (slot of sorted group g: ((g % cpj) + (g / cpj / T) * cpj) * T + (g / cpj) % T).  perm[slot] = batch row, slens[slot] =
 // its steps.  Up to three geometries in one launch.
 struct RowOrder { const int32_t* lens; int add, T, cpj; int32_t* perm; int32_t* slens; };
-hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S, int32_t* steps_sum = nullptr, int sum_rows = 0);      // steps_sum[0..1] <- sum of the first order's steps, sum_rows
+hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int Breal, int B, int S, int32_t* steps_sum = nullptr, int sum_rows = 0);      // steps_sum[0..1] <- sum of the first order's steps, sum_rows; B >= Breal slots: the rows beyond Breal are phantom rows of one step
 // dst[i,:] = src[idx[i],:] for i < *n_dev
 hipError_t rows_gather(hipStream_t st, float* dst, const float* src, const int32_t* idx, const int32_t* n_dev, int n_max, int D, const int32_t* map = nullptr);
 // dst[r,:] = rank[r] >= 0 ? src[rank[r],:] : 0   for r < rows

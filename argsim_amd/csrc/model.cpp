@@ -160,6 +160,11 @@ struct Ws {
     int32_t *map_src, *nact_src, *nsrc; bool compact;
     // the decoder's: map_tgt[(t, b)] over the positions t <= (last non-eos target position of row b) + 1, ntgt = how many
     int32_t *map_tgt, *nact_tgt, *ntgt; bool compact_d;
+    // rows of the GRU team kernels' launch geometry (gru_team_batch): = B where B itself has one, else the next row count that has;
+    // the slots beyond B hold phantom rows (GruArgs::Bx), which exist through the row order + the compact layout only
+    int Bx;
+    int bx_enc() const { return compact ? Bx : 0; }
+    int bx_dec() const { return compact_d ? Bx : 0; }
 };
 
 struct Bump {
@@ -225,13 +230,15 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     }
     {   // every GRU launch exchanges through the same scratch: the largest launch is both encoder directions (forward:
         // D floats per row and step, backward: 3D) or one decoder layer
-        const size_t rows = std::max<size_t>(2 * rs, rt);
+        const int bx = gru_team_batch(B);
+        w.Bx = bx > 0 ? bx : B;
+        const size_t rows = std::max<size_t>(2 * Ss, T) * (size_t)w.Bx;
         w.xbuf_floats = rows * D * (train ? 3 : 1);
         w.xbuf = b.take<float>(w.xbuf_floats);
     }
     w.map_src = b.take<int32_t>(rs); w.nact_src = b.take<int32_t>(Ss + 1); w.nsrc = b.take<int32_t>(4); w.compact = false;
     w.map_tgt = b.take<int32_t>(rt); w.nact_tgt = b.take<int32_t>(T + 1); w.ntgt = b.take<int32_t>(4); w.compact_d = false;
-    for (int k = 0; k < 3; ++k) { w.ord_perm[k] = b.take<int32_t>(B); w.ord_slens[k] = b.take<int32_t>(B); w.ord_ok[k] = false; w.ord_T[k] = w.ord_cpj[k] = 0; }
+    for (int k = 0; k < 3; ++k) { w.ord_perm[k] = b.take<int32_t>(w.Bx); w.ord_slens[k] = b.take<int32_t>(w.Bx); w.ord_ok[k] = false; w.ord_T[k] = w.ord_cpj[k] = 0; }
     w.hpick = b.take<float>((size_t)B * 2 * D);
     w.xlast = b.take<float>((size_t)B * 2 * D); w.gib = b.take<float>((size_t)B * 3 * D); w.svb = b.take<float>((size_t)B * 4 * D);
     w.dgib = b.take<float>(train ? (size_t)B * 3 * D : 0); w.dghb = b.take<float>(train ? (size_t)B * 3 * D : 0); w.dxl = b.take<float>(train ? (size_t)B * 2 * D : 0);
@@ -244,7 +251,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.dho = b.take<float>(rt * D); w.dhc = b.take<float>(rt * D);
         w.dhd[0] = b.take<float>(rt * D); w.dhd[1] = b.take<float>(rt * D);
         w.dgi_d = b.take<float>(rt * 3 * D); w.dgh_d = b.take<float>(rt * 3 * D);
-        w.dh0 = b.take<float>((size_t)L * B * D); w.carry = b.take<float>((size_t)3 * B * D);
+        w.dh0 = b.take<float>((size_t)L * B * D); w.carry = b.take<float>((size_t)3 * w.Bx * D);
         w.dh0sum = b.take<float>((size_t)B * D);
         w.dz = b.take<float>((size_t)B * R); w.dmu = b.take<float>((size_t)B * R); w.dlv = b.take<float>((size_t)B * R);
         w.dhpick = b.take<float>((size_t)B * 2 * D);
@@ -505,6 +512,7 @@ static void gru_common(avae_ctx* h, const Ws& w, GruArgs& a, int njobs, int S, i
 {
     const int D = h->cfg.dim_emb;
     a.njobs = njobs; a.S = S; a.B = B; a.D = D; a.ldg = ldg; a.ldh = ldh; a.lens = lens;
+    a.Bx = w.Bx;        // (shape queries: the geometry the team kernels would run with the row order and the compact layout in place)
     gru_geometry(D, njobs, B, &a.G, &a.rows_per_group);
     a.p_begin = 0; a.p_end = S; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow;
     a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item;
@@ -514,7 +522,8 @@ static void gru_common(avae_ctx* h, const Ws& w, GruArgs& a, int njobs, int S, i
 // kernels can skip padding, the batch rows sorted by length and dealt over the workgroups.  with_dec: the decoder runs too.
 int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
 {
-    if (!h->skip_pad || !h->persistent || B % 16) return 0;
+    if (!h->skip_pad || !h->persistent || w.Bx % 16) return 0;
+    if (w.Bx != B && !h->compact) return 0;                   // (phantom rows need the compact layout)
     const int D = h->cfg.dim_emb;
     RowOrder ord[3]; int n = 0, which[3];
     auto want = [&](int k, int njobs, int S, int ldg, int ldh, const int32_t* lens, int add) {
@@ -535,7 +544,7 @@ int build_row_orders(avae_ctx* h, Ws& w, int B, int Ss, int T, bool with_dec)
         if (hipHostMalloc(reinterpret_cast<void**>(&hp), 64, hipHostMallocDefault) == hipSuccess) { hp[0] = -1; hp[1] = 0; h->hint_host = hp; }
     }
     h->hint_dev = reinterpret_cast<int32_t*>(h->errw + 100);     // (spare words of the error block)
-    hipError_t e = row_order(h->stream, ord, n, B, std::max(Ss, T), hint ? h->hint_dev : nullptr, Ss * B);
+    hipError_t e = row_order(h->stream, ord, n, B, w.Bx, std::max(Ss, T), hint ? h->hint_dev : nullptr, Ss * B);
     if (e == hipErrorInvalidValue) return 0;                 // (a batch beyond the kernel's LDS: no order, every step runs)
     AV_CHECK(e);
     if (hint && h->hint_host) {
@@ -568,7 +577,9 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
 {
     w.compact = false; w.compact_d = false;
     if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B)) return 0;
-    if (h->compact == 2) {
+    const bool phantom = w.Bx != B;        // a batch without a team geometry of its own: the compact layout is what lets it run the team kernels at all
+    if (phantom && !(w.ord_ok[0] && (w.ord_ok[1] || !top_one_step(h)))) return 0;
+    if (h->compact == 2 && !phantom) {
         // auto: the layout pays where a good share of the padded positions is padding; on FULL batches the static row counts shape
         // the GEMM launches better (16.8 vs 17.3 ms at configs[1]).  The hint is an EARLIER call's count (no synchronisation).
         const int32_t real = h->hint_host ? h->hint_host[0] : -1, rows = h->hint_host ? h->hint_host[1] : 0;
@@ -586,6 +597,7 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
     w.compact = true;
     // the decoder stack the same way (training / evaluation calls: T > 1): a row's steps end one behind its last non-eos target id
     if (T < 2 || !use_table(h, T * B) || h->compact == 3) return 0;      // (3: the encoder alone, for measurements)
+    if (phantom && !w.ord_ok[2]) return 0;
     GruArgs q{};
     gru_common(h, w, q, 1, T, B, 3 * D, D, nullptr);
     int Tm = 0, cpj = 0, nrb = 0;
@@ -624,6 +636,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         }
         GruArgs a{};
         a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
+        a.Bx = w.bx_enc();
         gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         // table-fed layer: the team kernels read gi straight out of the per-id projection through a row index per token;
@@ -708,6 +721,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         }
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
+        a.Bx = compact ? w.Bx : 0;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
@@ -837,6 +851,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         const GruP& p = h->dec[i];
         GruArgs a{};
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
+        a.Bx = w.bx_dec();
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         GruJob& j = a.job[0];
@@ -925,13 +940,14 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         }
         GruArgs a{};
         a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
+        a.Bx = w.bx_enc();
         gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
         a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
         for (int d = 0; d < a.njobs; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
             j.dh_out = w.dhs[cur] + d * D; j.dgi = w.dgi_e + d * 3 * D; j.dgh = w.dgh_e + d * 3 * D;
-            j.dh0 = nullptr; j.carry = w.carry + (size_t)d * B * D;
+            j.dh0 = nullptr; j.carry = w.carry + (size_t)d * w.Bx * D;
             j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs)) && gru_backward_uses_team(a, h->persistent != 0);

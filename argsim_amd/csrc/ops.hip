@@ -519,15 +519,17 @@ hipError_t rows_expand(hipStream_t st, float* dst, const float* src, const int32
 // ---------------------------------------------------------------- final-state pick (tf.gather_nd, model.py:135)
 // ---------------------------------------------------------------- row order for the padding-skipping GRU kernels
 struct RowOrders { RowOrder o[3]; };
-__global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int B, int S, int32_t* __restrict__ steps_sum, int sum_rows)
+__global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int Breal, int B, int S, int32_t* __restrict__ steps_sum, int sum_rows)
 {
     extern __shared__ int steps[];                       // B ints
     const RowOrder o = ro.o[blockIdx.x];
-    for (int b = threadIdx.x; b < B; b += blockDim.x) steps[b] = min(max(o.lens[b] + o.add, 1), S);
+    // (B > Breal: the launch geometry has more slots than the batch has rows -- the rows beyond are PHANTOM rows of one step, sorted
+    //  behind every real row; GruArgs::Bx)
+    for (int b = threadIdx.x; b < B; b += blockDim.x) steps[b] = b < Breal ? min(max(o.lens[b] + o.add, 1), S) : 1;
     __syncthreads();
     if (steps_sum && blockIdx.x == 0 && threadIdx.x < 64) {      // real positions of the first order's id source (the host's fill hint)
         int v = 0;
-        for (int b = threadIdx.x; b < B; b += 64) v += steps[b];
+        for (int b = threadIdx.x; b < Breal; b += 64) v += steps[b];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (threadIdx.x == 0) { steps_sum[0] = v; steps_sum[1] = sum_rows; }      // (real positions, padded positions)
     }
@@ -541,13 +543,13 @@ __global__ __launch_bounds__(1024) void row_order_kernel(RowOrders ro, int B, in
         o.slens[slot] = mine;
     }
 }
-hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int B, int S, int32_t* steps_sum, int sum_rows)
+hipError_t row_order(hipStream_t st, const RowOrder* orders, int n, int Breal, int B, int S, int32_t* steps_sum, int sum_rows)
 {
     if (n <= 0) return hipSuccess;
-    if (n > 3 || B % 16 || (size_t)B * 4 > 64 * 1024) return hipErrorInvalidValue;
+    if (n > 3 || B % 16 || B < Breal || (size_t)B * 4 > 64 * 1024) return hipErrorInvalidValue;
     RowOrders ro{};
     for (int i = 0; i < n; ++i) ro.o[i] = orders[i];
-    hipLaunchKernelGGL(row_order_kernel, dim3(n), dim3(1024), (size_t)B * sizeof(int), st, ro, B, S, steps_sum, sum_rows);
+    hipLaunchKernelGGL(row_order_kernel, dim3(n), dim3(1024), (size_t)B * sizeof(int), st, ro, Breal, B, S, steps_sum, sum_rows);
     return hipGetLastError();
 }
 

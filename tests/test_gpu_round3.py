@@ -328,6 +328,14 @@ def test_bf16_nt_gemm_large_tile_form(M, N, K):
     (64, 256, 32, 3, 40, 14, 'f32'),        # small width: register-form kernels throughout
     (512, 8192, 128, 3, 256, 21, 'bf16'),   # bf16 storage paths at one row block per workgroup
     (512, 8192, 128, 2, 512, 11, 'bf16'),   # bf16, pipelined row blocks, two layers
+    # batches WITHOUT a team geometry of their own (the reference's batch_train 100 and batch_valid 200, src/config.json): the
+    # default path runs the team kernels on the next row count that has one, the slots beyond B holding phantom rows (GruArgs::Bx)
+    (512, 1024, 64, 3, 100, 21, 'f32'),     # 100 -> 128 slots
+    (512, 1024, 64, 3, 200, 12, 'f32'),     # 200 -> 256 slots
+    (512, 1024, 64, 2, 17, 70, 'f32'),      # 17 -> 32 slots: one team of real rows and one mixed
+    (512, 1024, 64, 3, 72, 30, 'f32'),      # 72 -> 96 slots
+    (512, 8192, 128, 3, 100, 90, 'bf16'),   # bf16 exchange, h0 seeded through the permutation
+    (512, 1024, 64, 3, 1000, 9, 'f32'),     # 1000 -> 1024 slots: pipelined row blocks
 ])
 def test_default_path_equals_the_graph_as_written(D, V, R, L, B, S, dtype):
     """Every exact elimination and storage choice of the default path switched off at once (table_l1, enc_top1, skip_pad, compact; bf16
