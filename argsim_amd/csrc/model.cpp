@@ -183,7 +183,18 @@ struct Bump {
 // (rows_group_sum) and runs dW = (sum)^T E_present and dE[present] += (sum) W over U rows.  The same products grouped by id:
 // exact algebra, a different summation order in the backward.  The compact E rows live in emb_src / emb_tgt (unused
 // otherwise in this mode), the per-id gradient of E in demb_src / demb_tgt.
-static bool use_table(const avae_ctx* h, int rows) { return h->table_l1 && rows >= h->cfg.dim_tgt && id_groups_supported(h->cfg.dim_tgt); }
+// A batch WITHOUT a team-kernel geometry of its own reaches the team kernels through the compact layout, which
+// needs the first layers table-fed: such a batch takes the table path below the vocabulary size as well (never more rows than
+// tokens: U <= rows).
+static bool phantom_batch(const avae_ctx* h, int B)
+{
+    return h->compact && h->skip_pad && h->persistent && h->cfg.dim_emb == 512 && gru_team_batch(B) > B;
+}
+static bool use_table(const avae_ctx* h, int rows, int B)
+{
+    if (!h->table_l1 || !id_groups_supported(h->cfg.dim_tgt)) return false;
+    return rows >= h->cfg.dim_tgt || (rows >= 1024 && phantom_batch(h, B));
+}
 
 void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
 {
@@ -195,7 +206,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
     w.emb_src = b.take<float>(rs * D); w.emb_tgt = b.take<float>(rt * D);
     // table-fed first layers (use_table), taken only where this geometry runs them: W E over the present ids ((U, 6D) encoder
     // layer 1, then (U, 3D) decoder layer 1), the token groups of the id source, the projection row of every token
-    const bool tab_s = use_table(h, (int)rs), tab_t = use_table(h, (int)rt);
+    const bool tab_s = use_table(h, (int)rs, B), tab_t = use_table(h, (int)rt, B);
     w.ew = b.take<float>(tab_s ? (size_t)V * 6 * D : (tab_t ? (size_t)V * 3 * D : 0));
     w.grp_src = b.take<int32_t>(tab_s ? id_groups_ints(rs, V) : 0); w.grp_tgt = b.take<int32_t>(tab_t ? id_groups_ints(rt, V) : 0);
     w.tokrow_src = b.take<int32_t>(tab_s ? rs : 0); w.tokrow_tgt = b.take<int32_t>(tab_t ? rt : 0);
@@ -576,7 +587,7 @@ static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
 int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
 {
     w.compact = false; w.compact_d = false;
-    if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B)) return 0;
+    if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B, B)) return 0;
     const bool phantom = w.Bx != B;        // a batch without a team geometry of its own: the compact layout is what lets it run the team kernels at all
     if (phantom && !(w.ord_ok[0] && (w.ord_ok[1] || !top_one_step(h)))) return 0;
     if (h->compact == 2 && !phantom) {
@@ -596,7 +607,7 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
     AV_CHECK(row_map(h->stream, w.lens_src, 0, Ss, B, w.map_src, w.nact_src, w.nsrc));
     w.compact = true;
     // the decoder stack the same way (training / evaluation calls: T > 1): a row's steps end one behind its last non-eos target id
-    if (T < 2 || !use_table(h, T * B) || h->compact == 3) return 0;      // (3: the encoder alone, for measurements)
+    if (T < 2 || !use_table(h, T * B, B) || h->compact == 3) return 0;      // (3: the encoder alone, for measurements)
     if (phantom && !w.ord_ok[2]) return 0;
     GruArgs q{};
     gru_common(h, w, q, 1, T, B, 3 * D, D, nullptr);
@@ -611,7 +622,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
 {
     const int D = h->cfg.dim_emb, V = h->cfg.dim_tgt, L = h->cfg.rnn_layers;
     const int rs = Ss * B;
-    const bool table = use_table(h, rs);
+    const bool table = use_table(h, rs, B);
     h->cnt_src = table ? id_groups_count(w.grp_src, rs, V) : nullptr;
     // compact layout (build_compact): every array between the GEMMs and the GRU launches holds the real rows only; the GEMMs over
     // them take the device-side row count
@@ -766,7 +777,7 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
     AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
-    if (use_table(h, rt)) AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train, w.lead, w.compact_d));
+    if (use_table(h, rt, B)) AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train, w.lead, w.compact_d));
     else {
         AV_CHECK(embed_gather(h->stream, h->P + h->oE, w.lead, w.emb_tgt, rt, D, V));
         AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train));
@@ -861,7 +872,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         j.dbW = G + p.bW; j.dbR = G + p.bR;
         // bf16 mode: the team kernels write the gate gradients as bf16, the operand of the three GEMMs below as it stands
         // (a table-fed layer keeps fp32: its gradients are summed by id first)
-        const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt)) && gru_backward_uses_team(a, h->persistent != 0);
+        const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt, B)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) { j.dgi16 = w.dgi16_d; j.dgh16 = w.dgh16_d; }
         if (w.acth_d[i]) j.hp16 = w.d_hp16[i];
         attach_sv16(h, a, true);
@@ -872,7 +883,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
-        if (i == 0 && use_table(h, rt)) {
+        if (i == 0 && use_table(h, rt, B)) {
             // table-fed layer: gate gradients summed by id, then dW = (sum)^T E and dE += (sum) W over V rows
             const int32_t* cnt = id_groups_count(w.grp_tgt, rt, V); const int U = std::min(V, rt);
             AV_CHECK(rows_group_sum(st, w.dew, w.lead, w.dgi_d, rt, 3 * D, V, w.grp_tgt));
@@ -950,7 +961,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             j.dh0 = nullptr; j.carry = w.carry + (size_t)d * w.Bx * D;
             j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
-        const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs)) && gru_backward_uses_team(a, h->persistent != 0);
+        const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs, B)) && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) for (int d = 0; d < a.njobs; ++d) { a.job[d].dgi16 = w.dgi16_e + d * 3 * D; a.job[d].dgh16 = w.dgh16_e + d * 3 * D; }
         if (w.acth_e[i]) for (int d = 0; d < a.njobs; ++d) a.job[d].hp16 = w.e_hp16[d][i];
         attach_sv16(h, a, true);
@@ -961,7 +972,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
-        const bool table = i == 0 && use_table(h, rs);
+        const bool table = i == 0 && use_table(h, rs, B);
         const float* x = i == 0 ? w.emb_src : w.e_hs[i - 1];
         float* dx = i == 0 ? w.demb_src : w.dhs[cur ^ 1];
         if (g16) {
@@ -969,7 +980,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             const int Gc = a.njobs * 3 * D;                          // gate columns of the directions that ran
             if (i == 0) {     // first layer (per-token form): input gradient, scatter, embedding bucket -- the fixed order of announcements
                 AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, nullptr, 0));
-                AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
+                AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, rs, w.lead, w.demb_tgt, use_table(h, rt, B) ? 0 : rt, D, V, w.scat));
                 fire_hook(h, 2 + 2 * L);
                 hook_flush(h);
             }
@@ -1001,7 +1012,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             } else
             AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
             // gather gradients of the per-token forms on top of the logits term (a table-fed side has added its rows already)
-            AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, table ? 0 : rs, w.lead, w.demb_tgt, use_table(h, rt) ? 0 : rt, D, V, w.scat));
+            AV_CHECK(embed_scatter_add2(st, G + h->oE, w.src_tm, w.demb_src, table ? 0 : rs, w.lead, w.demb_tgt, use_table(h, rt, B) ? 0 : rt, D, V, w.scat));
             fire_hook(h, 2 + 2 * L);
             hook_flush(h);
             if (table) {

@@ -13,11 +13,11 @@ def zipf_ids(rng, n, V):
     return (rng.choice(V - 3, size=n, p=p) + 3).astype(np.int32)
 
 
-def batch(B, S, V=8192, ragged=False, seed=0, eos=1):
+def batch(B, S, V=8192, ragged=False, seed=0, eos=1, len_median=24.0, len_sigma=0.5):
     rng = np.random.default_rng(seed)
     ids = zipf_ids(rng, B * S, V).reshape(B, S)
     if ragged:
-        lens = np.clip(np.rint(rng.lognormal(np.log(24.0), 0.5, B)), 2, S).astype(int)
+        lens = np.clip(np.rint(rng.lognormal(np.log(len_median), len_sigma, B)), 2, S).astype(int)
         for b, n in enumerate(lens):
             ids[b, n:] = eos
     return ids

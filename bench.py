@@ -77,14 +77,16 @@ def cpu_baseline(steps=5, warmups=2):
                        "absent and CudnnGRU is GPU-only) on the full %d x %d FULL batch of the headline workload" % (steps, warmups, b, s))
 
 
-def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None, **model_kw):
+def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None, ragged=None, **model_kw):
     """one of the other BASELINE configurations on this GPU, a few steps, with its kernel-class split (HIP events)"""
     import torch
     from argsim_amd import synth
     from argsim_amd.model import VAE
     m = VAE('train', device=torch.cuda.current_device(), seed=0, dtype=dtype, **dict(CFG, **model_kw))
     m.step = 20000
-    ids = torch.as_tensor(synth.batch(b, s, CFG['dim_tgt'], seed=0)).to(m.device)
+    # (ragged = (median, sigma): LogNormal row lengths clipped to [2, s], eos-padded to s and handed over untrimmed)
+    ids = torch.as_tensor(synth.batch(b, s, CFG['dim_tgt'], seed=0, **(dict(ragged=True, len_median=ragged[0], len_sigma=ragged[1]) if ragged else {}))).to(m.device)
+    n_real = int((ids != CFG.get('eos', 1)).sum()) if ragged else b * s
     for i in range(warmup):
         m.train_step(ids, ids, seed=i)
     torch.cuda.synchronize()
@@ -101,7 +103,7 @@ def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None, **model_kw):
     assert all(x == x and abs(x) < 1e6 for x in losses), losses
     peak = {'f32': PEAK_F32_MFMA, 'bf16': PEAK_BF16_MFMA, 'f32s': PEAK_BF16_MFMA / 6.0}[dtype]
     out = {"workload": label, "dtype": dtype, "batch": b, "seq_len": s, "steps": steps, "warmup": warmup,
-           "value": b / dt, "unit": "sentences/sec", "ms_per_step": 1e3 * dt, "loss": losses[2],
+           "value": b / dt, "unit": "sentences/sec", "ms_per_step": 1e3 * dt, "loss": losses[2], "real_tokens_per_batch": n_real,
            "classes": {k: {"ms_per_step": v[0], "launches_per_step": v[1], "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0)}
                        for k, v in tm.items()},
            "gemm_frac_of_peak": (tm['gemm'][2] / (tm['gemm'][0] * 1e-3) / 1e12 / peak) if tm['gemm'][0] > 0 else None,
@@ -355,6 +357,7 @@ def main():
                 "configs[2]": side_config("BASELINE configs[2]: 1xMI355X bf16 operands in the GEMMs and the GRU recurrence (fp32 accumulate/state), seq_len 128, batch 1024", 'bf16', 1024, 128, pmc='configs2'),
                 "configs[4]": side_config("BASELINE configs[4]: 1xMI355X fp32, latent_dim 512 with the beta / free-bits extension live (kl_beta 0.5, free_bits 0.02), seq_len 64, batch 256", 'f32', 256, 64, steps=10, dim_rep=512, kl_beta=0.5, free_bits=0.02),
                 "reference_training_geometry": side_config("the reference's own training geometry (src/config.json: batch_train 100, max_len 512, dim_rep 1024), FULL 512-piece rows, fp32 -- context for BASELINE.md section 1 (paper: ~1.14 s / step on an unstated NVIDIA GPU), not a BASELINE config", 'f32', 100, 512, steps=3, dim_rep=1024),
+                "reference_training_geometry_ragged": side_config("the same geometry (batch 100, rows padded to 512, dim_rep 1024) with RAGGED rows: lengths LogNormal(median 120, sigma 0.7) clipped to [2, 512] -- an ASSUMED post-length distribution (the corpora are not in the container); batch 100 has no team-kernel geometry of its own: 128 slots, 28 phantom rows (DESIGN 4.2f)", 'f32', 100, 512, steps=3, dim_rep=1024, ragged=(120.0, 0.7)),
                 "configs[3]/gpu": side_config("BASELINE configs[3] per-GPU load: fp32, batch 1024 (global 8192 over 8 GPUs), seq_len 64; the all-reduce is not part of it", 'f32', 1024, 64),
             }
         print(json.dumps(out))
