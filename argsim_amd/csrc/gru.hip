@@ -2097,12 +2097,13 @@ static bool team_rows(int njobs, int B, int* T, int* C)
     }
     return false;
 }
-// The smallest row count >= B the team kernels have a geometry for with one job AND with two (0: none within 64 rows): a
-// batch of any size runs them with that many slots, the slots beyond B holding phantom rows (GruArgs::Bx).
+// The smallest row count >= B the team kernels have a geometry for with one job AND with two (0: none within 256 rows -- every
+// batch up to 1024 rows has one): a batch of any size runs them with that many slots, the slots beyond B holding phantom rows
+// (GruArgs::Bx), which cost one step each.
 int gru_team_batch(int B)
 {
     int T = 0, C = 0;
-    for (int bx = (B + 15) / 16 * 16; bx <= B + 64; bx += 16)
+    for (int bx = (B + 15) / 16 * 16; bx <= B + 256; bx += 16)
         if (team_rows(1, bx, &T, &C) && team_rows(2, bx, &T, &C)) return bx;
     return 0;
 }

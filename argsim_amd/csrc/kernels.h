@@ -119,7 +119,7 @@ hipError_t gru_backward(hipStream_t st, const GruArgs& a, bool persistent);
 // geometry of the team kernels a launch of this shape would run: T teams of 16 rows per 16 T-row block, cpj chain groups
 // (workgroups) per job and hidden tile, nrb row blocks per workgroup; false: another kernel form runs (no slens / perm)
 bool gru_team_shape(const GruArgs& a, bool fwd, bool persistent, int* T, int* cpj, int* nrb);
-int gru_team_batch(int B);        // smallest row count >= B (within 64) the team kernels have a geometry for with one job and with two; 0: none
+int gru_team_batch(int B);        // smallest row count >= B (within 256) the team kernels have a geometry for with one job and with two; 0: none
 bool gru_backward_uses_team(const GruArgs& a, bool persistent);     // true: the launch runs the LDS-weight team kernels (dgi16 / dgh16 honoured in bf16 mode)
 bool gru_dim_supported(int D);
 // one GRU step from a zero state for B rows (the top encoder layer's backward direction: gru.hip "one step from a zero

@@ -1315,6 +1315,9 @@ int avae_timing_collect(avae_handle h, double* out)
     h->stamps_used = 0;
     return 0;
 }
+// rows of the launch geometry the GRU team kernels take for a batch of B rows (gru_team_batch: B itself, the next row count with a
+// geometry -- the slots beyond B hold phantom rows --, or 0).  Host arithmetic only: callable without a GPU.
+int avae_debug_team_batch(int32_t B) { return B > 0 ? gru_team_batch(B) : 0; }
 // ids present in the last forward's two id sources (encoder input, decoder input) where those layers were table-fed
 // (use_table), else -1: out[0] = src, out[1] = tgt.  Synchronises.
 int avae_debug_present_ids(avae_handle h, int32_t out[2])

@@ -56,6 +56,7 @@ SIGNATURES = {
     'avae_debug_timing': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     'avae_debug_stamps': (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     'avae_debug_present_ids': (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    'avae_debug_team_batch': (C.c_int, [C.c_int32]),
     'avae_bucket_count': (C.c_int, [_P]),
     'avae_bucket_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

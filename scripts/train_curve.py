@@ -29,11 +29,11 @@ def batch(seed):
 # MODES=round2: the default path (layers fed by embedding rows project the present ids) against the per-token
 # projection (table_l1 = 0) and the bf16-operand mode, same seeds
 # MODES=round3: the default path against the reference's graph executed as written (table_l1 = 0, enc_top1 = 0: all steps of the top
-# encoder layer's backward direction, skip_pad = 0: every step of every row) and the bf16-operand mode (bf16 gate gradients, saved
+# encoder layer's backward direction, skip_pad = 0: every step of every row, compact = 0: the padded layout) and the bf16-operand mode (bf16 gate gradients, saved
 # gates, h / h_prev; transposing-load GEMMs), same seeds
 ROUND2 = os.environ.get('MODES') in ('round2', 'round3')
 RUNS = (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0}), ('f32s', 'bf16', {})) if os.environ.get('MODES') == 'round2' else \
-       (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0, 'enc_top1': 0, 'skip_pad': 0}), ('f32s', 'bf16', {})) if os.environ.get('MODES') == 'round3' else \
+       (('f32', 'f32', {}), ('f32 again', 'f32', {'table_l1': 0, 'enc_top1': 0, 'skip_pad': 0, 'compact': 0}), ('f32s', 'bf16', {})) if os.environ.get('MODES') == 'round3' else \
        (('f32', 'f32', {}), ('f32 again', 'f32', {}), ('f32s', 'f32s', {}))
 curves = {}
 for tag, dt, opts in RUNS:

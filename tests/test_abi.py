@@ -53,6 +53,20 @@ def test_create_fails_loudly_without_gpu():
         VAE('train', dim_tgt=32, dim_emb=16, dim_rep=8)
 
 
+def test_team_kernel_launch_geometry_for_any_batch_size():
+    """the GRU team kernels run a batch without a geometry of its own on the next row count that has one (phantom
+    rows in the slots beyond B).  Host arithmetic of the library, no GPU: the reference's batch_train 100 and batch_valid 200
+    (src/config.json) among them; every batch of up to 1024 rows has a geometry within 256 rows, a multiple of 16 and >= B."""
+    from argsim_amd import lib
+    l = lib.load()
+    want = {64: 64, 128: 128, 256: 256, 512: 512, 1024: 1024, 100: 128, 200: 256, 17: 32, 72: 96, 1000: 1024, 1: 32, 48: 64, 300: 384, 576: 768, 2048: 0}
+    got = {b: l.avae_debug_team_batch(b) for b in want}
+    assert got == want, got
+    for b in range(1, 1025):
+        bx = l.avae_debug_team_batch(b)
+        assert b <= bx <= b + 256 and bx % 16 == 0, (b, bx)
+
+
 def test_unsupported_reference_branches_are_rejected():
     from argsim_amd.model import _check_cfg
     _check_cfg(True, True, False, True)

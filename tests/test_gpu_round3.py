@@ -338,6 +338,8 @@ def test_bf16_nt_gemm_large_tile_form(M, N, K):
     (512, 1024, 64, 3, 1000, 9, 'f32'),     # 1000 -> 1024 slots: pipelined row blocks
     (512, 8192, 128, 3, 100, 30, 'f32'),    # fewer tokens than vocabulary entries: such a batch is table-fed all the same (use_table)
     (512, 8192, 128, 3, 200, 12, 'bf16'),
+    (512, 1024, 64, 3, 300, 10, 'f32'),     # 300 -> 384 slots (three 64-row blocks per job pair / 32-row blocks)
+    (512, 1024, 64, 2, 576, 6, 'bf16'),     # 576 -> 768 slots: three pipelined row blocks, a quarter of the slots phantom
 ])
 def test_default_path_equals_the_graph_as_written(D, V, R, L, B, S, dtype):
     """Every exact elimination and storage choice of the default path switched off at once (table_l1, enc_top1, skip_pad, compact; bf16
