@@ -593,7 +593,9 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
     if (h->compact == 2 && !phantom) {
         // auto: the layout pays where a good share of the padded positions is padding; on FULL batches the static row counts shape
         // the GEMM launches better (16.8 vs 17.3 ms at configs[1]).  The hint is an EARLIER call's count (no synchronisation).
-        const int32_t real = h->hint_host ? h->hint_host[0] : -1, rows = h->hint_host ? h->hint_host[1] : 0;
+        // (both words in ONE 8-byte load: the copy that lands them is 8 bytes, so a pair is never half of one call and half of another)
+        const uint64_t pair = h->hint_host ? *reinterpret_cast<const volatile uint64_t*>(h->hint_host) : 0xffffffffull;
+        const int32_t real = (int32_t)(uint32_t)(pair & 0xffffffffull), rows = (int32_t)(uint32_t)(pair >> 32);
         if (real < 0 || rows <= 0 || (double)real >= 0.85 * (double)rows) return 0;
     }
     const int D = h->cfg.dim_emb;
