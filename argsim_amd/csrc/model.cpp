@@ -582,8 +582,10 @@ static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
     a.slens = w.ord_slens[k]; a.perm = w.ord_perm[k];
 }
 
-// Compact encoder layout of this call: possible where every encoder GRU launch runs the team kernels (they address the
-// external arrays through GruArgs::rowmap) and the first layer is table-fed (its per-token arrays keep the padded order).
+// Compact layout of this call, decided for the encoder stack and, with T > 1, for the decoder stack: possible where
+// every GRU launch of the stack runs the team kernels (they address the external arrays through GruArgs::rowmap) and its first
+// layer is table-fed (its per-token arrays keep the padded order).  Taken when the fill hint says the batch is ragged, and
+// always for a batch without a team-kernel geometry of its own, which reaches the team kernels through it (Ws::Bx).
 int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
 {
     w.compact = false; w.compact_d = false;
