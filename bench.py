@@ -309,7 +309,8 @@ def main():
                     model.train_step(ids_rd, ids_rd, seed=50 + i)
                 fence()
                 dtr = (time.perf_counter() - t1) / A.steps
-                model.set_option('skip_pad', 0)          # the same batch with every step of every row run (padding not skipped)
+                model.set_option('skip_pad', 0)          # the same batch with every step of every row run on the padded layout
+                model.set_option('compact', 0)           # (padding neither skipped in the recurrence nor dropped between the GEMMs and the GRU launches)
                 for i in range(2):
                     model.train_step(ids_rd, ids_rd, seed=i)
                 fence()
@@ -319,6 +320,7 @@ def main():
                 fence()
                 dtr0 = (time.perf_counter() - t1) / A.steps
                 model.set_option('skip_pad', 1)
+                model.set_option('compact', 2)
                 out["ragged"] = {"ms_per_step_every_step_run": 1e3 * dtr0,"value": B / dtr, "unit": "sentences/sec", "tokens_per_sec": tok_r / dtr, "ms_per_step": 1e3 * dtr,
                                  "mean_len": float((ids_r != 1).sum(1).mean()), "max_len": int((ids_r != 1).sum(1).max()),
                                  "padded_step_share": 1.0 - float((ids_r != 1).sum()) / float(B * int((ids_r != 1).sum(1).max())),
