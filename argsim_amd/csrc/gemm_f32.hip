@@ -386,6 +386,76 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_persist_kernel(GemmArgs g)
     }
 }
 
+// Skinny problems (a few hundred rows: the latent block, the one-step top layer, the remainder rows of a big GEMM): the tiled
+// kernel above spends a K tile's staging latency on a handful of MFMAs and runs at 4-40 TFLOP/s there.  Here a workgroup owns
+// ONE 32x32 output tile and its 8 waves split K eight ways: every wave loads its operand slices straight into the MFMA
+// register layout (no LDS staging, no barrier in the loop: the operands are a few hundred KB and live in L2), the eight partial
+// tiles meet in LDS once and wave 0 adds them in a fixed order -- deterministic, no atomics.  A k-contiguous ([M][K]); B either
+// k-contiguous ([N][K]) or [K][N].
+template <bool B_NC>
+__global__ __launch_bounds__(512) void gemm_f32_skinny_kernel(GemmArgs g)
+{
+    __shared__ float red[7][16][64];
+    if (blockIdx.y) { g.A = g.A2; g.B = g.B2; g.C = g.C2; g.bias = g.bias2; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tiles_n = (g.N + 31) / 32, tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int kchunk = ((g.K + 63) / 64) * 8;                       // ceil(K / 8) rounded up to the 8 k of one iteration
+    const int k0 = wave * kchunk, k1 = min(g.K, k0 + kchunk);
+    const float* __restrict__ ap = g.A + (size_t)min(m0 + l31, g.M - 1) * g.lda;
+    const int bcol = min(n0 + l31, g.N - 1);
+    const float* __restrict__ bp = B_NC ? g.B + bcol : g.B + (size_t)bcol * g.ldb;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // lane (l31, h) feeds k = kk + 4 h + {0..3} of an 8-wide step: A[row l31][k] and B[k][col l31] (any pairing of k indices is a
+    // valid contraction order as long as both operands use the same one)
+    for (int kk = k0; kk < k1; kk += 8) {
+        const int k = kk + 4 * h;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k1) {                                               // (K and the chunks are multiples of 4: a whole float4 or nothing)
+            a = *reinterpret_cast<const float4*>(ap + k);
+            if constexpr (B_NC) {
+                b.x = bp[(size_t)k * g.ldb]; b.y = bp[(size_t)(k + 1) * g.ldb]; b.z = bp[(size_t)(k + 2) * g.ldb]; b.w = bp[(size_t)(k + 3) * g.ldb];
+            } else b = *reinterpret_cast<const float4*>(bp + k);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int col = n0 + l31;
+    if (col >= g.N) return;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int w = 0; w < 7; ++w) v += red[w][r][lane];           // fixed order: the same bits every run
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float* c = g.C + (size_t)row * g.ldc + col;
+        v = g.alpha * v + bv;
+        if (g.accumulate) *c += v; else *c = v;
+    }
+}
+static bool skinny_ok(bool a_mc, const GemmArgs& g)
+{
+    return !a_mc && g.split_k <= 1 && g.dyn_kind == 0 && (g.K & 3) == 0 && (g.lda & 3) == 0 && g.K >= 64;
+}
+static void launch_skinny(hipStream_t st, bool b_nc, const GemmArgs& g)
+{
+    dim3 grid(((g.M + 31) / 32) * ((g.N + 31) / 32), g.A2 ? 2 : 1);
+    if (b_nc) hipLaunchKernelGGL(gemm_f32_skinny_kernel<true>, grid, dim3(512), 0, st, g);
+    else      hipLaunchKernelGGL(gemm_f32_skinny_kernel<false>, grid, dim3(512), 0, st, g);
+}
+
 template <int WM, int WN, int TM, int TN>
 static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
 {
@@ -461,7 +531,9 @@ hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g)
     if (!b_nc && (g.K & 3)) return hipErrorInvalidValue;
     if (b_nc && (g.N & 3)) return hipErrorInvalidValue;
     // (256x128 and 128x256 tiles were measured 5-20 % slower: 1 workgroup per CU cannot hide its own staging)
-    if (g.thin == 2) launch_variant<2, 2, 1, 1>(st, a_mc, b_nc, g);      // 64x64 tiles: 4x the tiles of the 128x128 form -> a quarter of the split-K slices
+    if (g.thin == 3 && skinny_ok(a_mc, g) && (b_nc || (g.ldb & 3) == 0)) launch_skinny(st, b_nc, g);      // a few rows: one 32x32 tile per workgroup, K split over its waves
+    else if (g.thin == 3) launch_variant<1, 4, 1, 1>(st, a_mc, b_nc, g);
+    else if (g.thin == 2) launch_variant<2, 2, 1, 1>(st, a_mc, b_nc, g);      // 64x64 tiles: 4x the tiles of the 128x128 form -> a quarter of the split-K slices
     else if (g.thin) launch_variant<1, 4, 1, 1>(st, a_mc, b_nc, g);
     else        launch_variant<2, 2, 2, 2>(st, a_mc, b_nc, g);
     return hipGetLastError();

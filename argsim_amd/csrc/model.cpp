@@ -49,6 +49,9 @@ struct avae_ctx {
     int persistent = 1;
     bool first_step_checked = false;
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
+    int skinny = 1;       // a few rows (latent block, one-step top layer; backward: remainder rows, small products): one 32x32 tile per workgroup,
+                          // K split over its waves (gemm_f32.hip); 0: the tiled forms
+    int rows_form = 0;    // one-shot: the next gemm() call's rows are the batch rows -- skinny form whatever the batch size (see gemm)
     int compact = 2;      // encoder activations stored over the REAL rows only (row_map / GruArgs::rowmap): padded rows of a ragged batch cost nothing in the
                           // encoder's GEMMs.  0 off, 1 on, 2 auto: on where the share of real positions the previous calls reported is below 0.85 (fill_hint)
     int skip_pad = 1;     // team GRU kernels skip the steps behind a row block's longest row (rows sorted by length, ops.hip row_order); 0: every step of every row
@@ -412,8 +415,18 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
     unsigned short* const keep = h->keep_a16;           // (bf16 mode: where the converted A operand is to stay, see gemm_raw)
     if (split_k != 0 || a_mc || dyn_kind == 2)
         return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, split_k ? split_k : 1, dyn, dyn_kind);
+    // The skinny form (gemm_f32.hip: one 32x32 tile per workgroup, K split over its waves) sums K in another order than the tiled
+    // kernels, so WHICH form a forward product takes must not depend on the batch: z and the per-token losses of a row are the
+    // same bits in a batch of 16 and of 1024 (test_large_batch_rows_are_independent).  Forward: only the call sites whose rows
+    // are the batch rows themselves ask for it (rows_form), for every batch size.  Backward (allow_atomic: the gradients carry
+    // float-atomic order anyway): a few rows over a moderate K take it instead of a zero fill + split-K atomics.
+    const bool rows_form = h->rows_form != 0; h->rows_form = 0;
+    if (rows_form && h->skinny && h->cfg.compute_dtype != 1 && !a_mc && split_k == 0 && dyn_kind == 0)
+        return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, nullptr, 0, 3);
+    const bool prefer_skinny = allow_atomic && h->skinny && M <= 512 && K <= 2048 && h->cfg.compute_dtype != 1;
+    const int thin_form = (allow_atomic && h->skinny) ? 3 : 1;
     if (tiles <= 96) {
-        if (allow_atomic && !accumulate && ldc == N && K >= 512) {
+        if (allow_atomic && !accumulate && ldc == N && K >= 512 && !prefer_skinny) {
             int s = std::min(768 / tiles, K / 128);
             if (s >= 2) {
                 AV_CHECK(zero_fill(h->stream, C, sizeof(float) * (size_t)M * N));
@@ -421,7 +434,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
             }
         }
         if (M <= 512)
-            return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 1);
+            return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, thin_form);      // (3: the skinny form where it applies, else 32x128 tiles)
     }
     // A GEMM whose row count is only known on the device (the ids present in the batch: about V / 2 of the static bound
     // of V rows) with a narrow output: 128x128 tiles over the rows that exist are fewer than one round of the chip (dE of
@@ -440,7 +453,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
             // rows beyond the device-side row count hold unread garbage either way: the tail keeps the static bound
             const float* At = A + (size_t)main_rows * lda; float* Ct = C + (size_t)main_rows * ldc;
             if (keep) h->keep_a16 = keep + (size_t)main_rows * K;
-            if (allow_atomic && !accumulate && ldc == N && K >= 1024) {
+            if (allow_atomic && !accumulate && ldc == N && K >= 1024 && !(h->skinny && K <= 2048 && h->cfg.compute_dtype != 1)) {
                 // backward only: a few rows x a long K (dho: 256 rows x K = 8192 took 0.2 ms on 32 thin tiles):
                 // K split over ~768 workgroups of full tiles with float atomics instead
                 const int s = std::min(768 / (((tail_rows + 127) / 128) * nt), K / 128);
@@ -449,7 +462,7 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
                     return gemm_raw(h, a_mc, b_nc, At, lda, Bm, ldb, Ct, ldc, tail_rows, N, K, alpha, bias, 0, s, nullptr, 0);
                 }
             }
-            return gemm_raw(h, a_mc, b_nc, At, lda, Bm, ldb, Ct, ldc, tail_rows, N, K, alpha, bias, accumulate, 1, nullptr, 0, 1);
+            return gemm_raw(h, a_mc, b_nc, At, lda, Bm, ldb, Ct, ldc, tail_rows, N, K, alpha, bias, accumulate, 1, nullptr, 0, thin_form);
         }
     }
     return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind);
@@ -686,6 +699,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
             if (w.act_e[i - 1]) AV_CHECK(pick_last16(h->stream, w.xlast, w.e_hs16[i - 1], w.lens_src, B, In, cmap));
             else
             AV_CHECK(pick_last(h->stream, w.xlast, x, w.lens_src, B, In, cmap));
+            h->rows_form = 1;
             AV_TRY(gemm(h, false, false, w.xlast, In, h->P + oWb, In, w.gib, 3 * D, B, 3 * D, In, 1.f, h->P + p.bW + 3 * D));
         }
         x = w.e_hs[i]; In = 2 * D;
@@ -703,7 +717,7 @@ int run_latent(avae_ctx* h, Ws& w, int B, bool train, uint64_t seed, const float
     const int D = h->cfg.dim_emb, R = h->cfg.dim_rep;
     {   // mu and lv (model.py:149-150): two affines of the same input, one launch
         const Pair lv{w.hpick, h->P + h->oWlv, w.lv, h->P + h->oBlv};
-        AV_TRY(gemm_raw(h, false, true, w.hpick, 2 * D, h->P + h->oWmu, R, w.mu, R, B, R, 2 * D, 1.f, h->P + h->oBmu, 0, 1, nullptr, 0, B <= 512 ? 1 : 0, &lv));
+        AV_TRY(gemm_raw(h, false, true, w.hpick, 2 * D, h->P + h->oWmu, R, w.mu, R, B, R, 2 * D, 1.f, h->P + h->oBmu, 0, 1, nullptr, 0, h->skinny ? 3 : (B <= 512 ? 1 : 0), &lv));      // (rows = the batch rows: the skinny form for every batch size)
     }
     AV_CHECK(latent_fwd(h->stream, w.mu, w.lv, eps, w.eps, w.z, w.kld, B * R, train ? 1 : 0, seed, h->cfg.free_bits, h->acc + 1));
     return 0;
@@ -780,6 +794,7 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     AV_TRY(build_compact(h, w, B, Ss, T, train));
     AV_TRY(run_encoder(h, w, B, Ss, train));
     AV_TRY(run_latent(h, w, B, train, seed, eps));
+    h->rows_form = 1;
     AV_TRY(gemm(h, false, true, w.z, R, h->P + h->oWex, D, w.h0, D, B, D, R, 1.f, h->P + h->oBex));
     if (use_table(h, rt, B)) AV_TRY(run_decoder_rnn(h, w, B, T, w.h0, 0, train, w.lead, w.compact_d));
     else {
@@ -1272,6 +1287,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "dyn_thin")) { h->dyn_thin = value != 0; return 0; }
     if (!strcmp(key, "skip_pad")) { h->skip_pad = value != 0; return 0; }
     if (!strcmp(key, "compact")) { h->compact = value; return 0; }
+    if (!strcmp(key, "skinny")) { h->skinny = value; return 0; }
     if (!strcmp(key, "gru_ablate")) {
         // timing experiments that change results exist only in the diagnostic build (make DIAG=1)
         if (value && !gru_diag_build()) return fail(h, "gru_ablate needs the diagnostic build of libargsim_vae.so (make -C argsim_amd/csrc DIAG=1)");
@@ -1365,8 +1381,8 @@ int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const flo
                     int M, int N, int K, int lda, int ldb, int ldc, float alpha, int accumulate, int split_k)
 {
     if (!h) return 1;
-    // split_k == -1 selects the thin (32x128 tile) variant, 1000 + s the 64x64-tile variant with s K slices
-    return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : (split_k >= 1000 ? split_k - 1000 : split_k), nullptr, 0, split_k < 0 ? 1 : (split_k >= 1000 ? 2 : 0));
+    // split_k == -1 selects the thin (32x128 tile) variant, -3 the skinny form, 1000 + s the 64x64-tile variant with s K slices
+    return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : (split_k >= 1000 ? split_k - 1000 : split_k), nullptr, 0, split_k == -3 ? 3 : (split_k < 0 ? 1 : (split_k >= 1000 ? 2 : 0)));
 }
 // test hook: C (M x N) += alpha * A^T B with A (K x M, lda), B (K x N, ldb) fp32 row-major, operands rounded to bf16 row by
 // row and read through the transposing-LDS-load GEMM (gemm_tn16 / gemm_bf16_tn); C must hold the value to add onto
@@ -1482,6 +1498,7 @@ int avae_decode_init(avae_handle h, const float* z, int32_t b, float* state_out)
     AV_TRY(check_bound(h));
     AV_CHECK(hipSetDevice(h->device));
     const int D = h->cfg.dim_emb, R = h->cfg.dim_rep, L = h->cfg.rnn_layers;
+    h->rows_form = 1;
     AV_TRY(gemm(h, false, true, z, R, h->P + h->oWex, D, state_out, D, b, D, R, 1.f, h->P + h->oBex));
     for (int i = 1; i < L; ++i)
         AV_CHECK(hipMemcpyAsync(state_out + (size_t)i * b * D, state_out, (size_t)b * D * sizeof(float), hipMemcpyDeviceToDevice, h->stream));

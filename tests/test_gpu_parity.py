@@ -54,7 +54,7 @@ def test_gemm(a_mc, b_nc, M, N, K):
     bt = torch.tensor(bias, device=dev)
     lda = M if a_mc else K
     ldb = N if b_nc else K
-    for acc, split in ((0, 1), (1, 1), (0, 3), (0, -1), (1, -1)):      # split -1: thin 32x128 tile variant
+    for acc, split in ((0, 1), (1, 1), (0, 3), (0, -1), (1, -1), (0, -3), (1, -3)):      # split -1: thin 32x128 tile variant; -3: skinny form (A k-contiguous), else thin
         Ct = torch.tensor(C0, device=dev) if acc else torch.zeros((M, N), device=dev)
         rc = l.avae_debug_gemm(h, a_mc, b_nc, At.data_ptr(), Bt.data_ptr(), Ct.data_ptr(), bt.data_ptr(),
                                M, N, K, lda, ldb, N, 0.5, acc, split)
