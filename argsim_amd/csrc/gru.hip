@@ -1622,12 +1622,13 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             if (CMP && ge >= Bs) continue;                         // (a phantom row: no external row)
             for (int p = nst_of(r); p < a.p_end; ++p) {
                 const unsigned orow = (((unsigned)p * (unsigned)Bs + (unsigned)ge) * (unsigned)ldg + ht * 48 + gn * 3) * 4u;
-                if (BF && p_dgi16 != nullptr) {
+                if (BF && p_dgh16 != nullptr) {          // (dgh as bf16; dgi as bf16 too, or fp32 for a table-fed layer: summed by id first)
                     if ((gn & 1) == 0) {
                         const u32x3 z3 = {0u, 0u, 0u};
                         if (!rowmap) __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgh16, (int)(orow >> 1), 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgi16, (int)(orow >> 1), 0, 0);
+                        if (p_dgi16 != nullptr) __builtin_amdgcn_raw_buffer_store_b96(z3, rs_dgi16, (int)(orow >> 1), 0, 0);
                     }
+                    if (p_dgi16 == nullptr) bstore3(0.f, 0.f, 0.f, rs_dgi, orow);
                 } else { if (!rowmap) bstore3(0.f, 0.f, 0.f, rs_dghw, orow); bstore3(0.f, 0.f, 0.f, rs_dgi, orow); }
             }
         }
@@ -1820,8 +1821,8 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
             }
             const unsigned orow = (rix * (unsigned)ldg + ht * 48 + gn_l * 3) * 4u;
             const unsigned orow_i = dgi_by_pos ? (prix * (unsigned)ldg + ht * 48 + gn_l * 3) * 4u : orow;      // dgi's own row (padded layout kept for a table-fed layer)
-            if (BF && p_dgi16 != nullptr) {
-                // 16-bit row-major copies: the even unit's lane takes its odd neighbour's three values (quad-permute DPP: lanes
+            if (BF && p_dgh16 != nullptr) {
+                // 16-bit row-major copies (dgi16 absent: a table-fed layer, whose dgi stays fp32 for the sum by id): the even unit's lane takes its odd neighbour's three values (quad-permute DPP: lanes
                 // 0,2 read lanes 1,3) and stores the six bf16 of both units as one 12-byte access
                 const float dnr = dn * r_;
                 const float o_r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dr), 0xF5, 0xF, 0xF, false));
@@ -1832,8 +1833,9 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
                     const u32x3 vh = {pack_bf16(dr, du), pack_bf16(dnr, o_r), pack_bf16(o_u, o_nr)};
                     const u32x3 vi = {pack_bf16(dr, du), pack_bf16(dn, o_r), pack_bf16(o_u, o_n)};
                     if (real) __builtin_amdgcn_raw_buffer_store_b96(vh, rs_dgh16, (int)(orow >> 1), 0, 0);
-                    if (real || (dgi_by_pos && inb)) __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow_i >> 1), 0, 0);
+                    if (p_dgi16 != nullptr && (real || (dgi_by_pos && inb))) __builtin_amdgcn_raw_buffer_store_b96(vi, rs_dgi16, (int)(orow_i >> 1), 0, 0);
                 }
+                if (p_dgi16 == nullptr && (real || (dgi_by_pos && inb))) bstore3(dr, du, dn, rs_dgi, orow_i);
                 if constexpr (PIPE) { const float c1 = dH * u; if (r == 0) carry_r0 = c1; else if (r == 1) carry_r1 = c1; else if (r == 2) carry_r2 = c1; else carry_r3 = c1; }
                 else carry_reg = dH * u;
             } else {

@@ -686,8 +686,8 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         }
         attach_sv16(h, a, save);
         if (w.e_hs16[i] && tn16_ok(h, 3 * D, D) && both_team_bf16(h, a, save)) {      // h / h_prev as bf16 (a table-fed layer keeps h_prev fp32: its dR runs the fp32-operand path)
-            w.act_e[i] = 1; w.acth_e[i] = !table0;
-            for (int d = 0; d < a.njobs; ++d) { a.job[d].hs16 = w.e_hs16[i] + d * D; if (!table0) a.job[d].hp16 = w.e_hp16[d][i]; }
+            w.act_e[i] = 1; w.acth_e[i] = 1;
+            for (int d = 0; d < a.njobs; ++d) { a.job[d].hs16 = w.e_hs16[i] + d * D; a.job[d].hp16 = w.e_hp16[d][i]; }
         }
         attach_order(h, w, a, true, top1 ? 1 : 0);
         a.rowmap = cmap;
@@ -767,7 +767,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         attach_sv16(h, a, save);
         if (w.d_hp16[i] && tn16_ok(h, 3 * D, D) && both_team_bf16(h, a, save)) {      // (the top layer keeps its fp32 output: the compaction and the out affine's gradient read it)
             if (i < L - 1) { w.act_d[i] = 1; j.hs16 = w.d_hd16[i]; }
-            if (!table0) { w.acth_d[i] = 1; j.hp16 = w.d_hp16[i]; }
+            w.acth_d[i] = 1; j.hp16 = w.d_hp16[i];       // (a table-fed layer too: its dR reads bf16 dgh and this, gemm_tn16)
         }
         if (T > 1) attach_order(h, w, a, true, 2);
         a.rowmap = cmap;
@@ -892,7 +892,11 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         // bf16 mode: the team kernels write the gate gradients as bf16, the operand of the three GEMMs below as it stands
         // (a table-fed layer keeps fp32: its gradients are summed by id first)
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rt, B)) && gru_backward_uses_team(a, h->persistent != 0);
+        // (a table-fed layer: dgh alone as bf16 -- its dR GEMM reads it and the bf16 h_prev as they stand; dgi stays fp32 for the sum by id)
+        const bool gh16 = !g16 && w.dgh16_d && tn16_ok(h, 3 * D, D) && a.bf16 && w.acth_d[i] && gru_backward_uses_team(a, h->persistent != 0);
         if (g16) { j.dgi16 = w.dgi16_d; j.dgh16 = w.dgh16_d; }
+        if (gh16) j.dgh16 = w.dgh16_d;
+        if (!g16 && !gh16 && w.acth_d[i]) return fail(h, "internal: the forward kept this layer's h_prev as bf16 only and the backward cannot read it");
         if (w.acth_d[i]) j.hp16 = w.d_hp16[i];
         attach_sv16(h, a, true);
         attach_order(h, w, a, false, 2);
@@ -907,6 +911,8 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             const int32_t* cnt = id_groups_count(w.grp_tgt, rt, V); const int U = std::min(V, rt);
             AV_CHECK(rows_group_sum(st, w.dew, w.lead, w.dgi_d, rt, 3 * D, V, w.grp_tgt));
             AV_TRY(gemm_tn_grad(h, w.dew, 3 * D, w.emb_tgt, D, G + p.W, D, 3 * D, D, U, 1.f, cnt));
+            if (gh16) AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, w.d_hp16[i], nullptr, D, G + p.R, D, 3 * D, D, rt, 1.f, ddyn));
+            else
             AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, ddyn));
             AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, w.demb_tgt, D, U, D, 3 * D, 1.f, nullptr, 0, 0, cnt, 1));
             AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
@@ -981,7 +987,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             j.dbW = G + p.bW + d * 3 * D; j.dbR = G + p.bR + d * 3 * D;
         }
         const bool g16 = tn16_ok(h, 3 * D, D) && a.bf16 && !(i == 0 && use_table(h, rs, B)) && gru_backward_uses_team(a, h->persistent != 0);
+        const bool gh16 = !g16 && w.dgh16_e && tn16_ok(h, 3 * D, D) && a.bf16 && w.acth_e[i] && gru_backward_uses_team(a, h->persistent != 0);      // (table-fed layer: see the decoder)
         if (g16) for (int d = 0; d < a.njobs; ++d) { a.job[d].dgi16 = w.dgi16_e + d * 3 * D; a.job[d].dgh16 = w.dgh16_e + d * 3 * D; }
+        if (gh16) for (int d = 0; d < a.njobs; ++d) a.job[d].dgh16 = w.dgh16_e + d * 3 * D;
+        if (!g16 && !gh16 && w.acth_e[i]) return fail(h, "internal: the forward kept this layer's h_prev as bf16 only and the backward cannot read it");
         if (w.acth_e[i]) for (int d = 0; d < a.njobs; ++d) a.job[d].hp16 = w.e_hp16[d][i];
         attach_sv16(h, a, true);
         attach_order(h, w, a, false, top1 ? 1 : 0);
@@ -1044,7 +1053,10 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             AV_TRY(gemm_tn_grad(h, w.dgib, 3 * D, w.xlast, In, G + oWb, In, 3 * D, In, B));              // backward direction's: B rows
         } else
         AV_TRY(gemm_tn_grad(h, w.dgi_e, 6 * D, x, In, G + p.W, In, 6 * D, In, rs, 1.f, cdyn));
-        if (top1) AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, cdyn));
+        if (gh16) {
+            for (int d = 0; d < a.njobs; ++d)
+                AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, w.e_hp16[d][i], nullptr, D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, cdyn));
+        } else if (top1) AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, cdyn));
         else {   // dR of the two directions: same shape, one launch
             const Pair bwd{w.dgh_e + 3 * D, w.e_hp[1][i], G + p.R + (int64_t)3 * D * D, nullptr};
             AV_TRY(gemm_tn_grad(h, w.dgh_e, 6 * D, w.e_hp[0][i], D, G + p.R, D, 3 * D, D, rs, 1.f, cdyn, &bwd));

@@ -8,8 +8,9 @@ from argsim_amd.model import VAE
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 m = VAE('train', seed=0, dtype=dt, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 m.step = 20000
-ids = torch.as_tensor(synth.batch(256, 64, 8192, ragged=bool(os.environ.get('RAGGED')), seed=0)).cuda()
-print('tokens incl. eos:', int((ids != 1).sum()) + 256)
+BB, SS = int(os.environ.get('B', '256')), int(os.environ.get('S', '64'))
+ids = torch.as_tensor(synth.batch(BB, SS, 8192, ragged=bool(os.environ.get('RAGGED')), seed=0)).cuda()
+print('tokens incl. eos:', int((ids != 1).sum()) + BB)
 for i in range(3): m.train_step(ids, ids, seed=i)
 m.set_option('timing', 1)
 m.train_step(ids, ids, seed=9)
