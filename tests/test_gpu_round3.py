@@ -96,7 +96,7 @@ def test_two_ranks_whose_shards_straddle_the_table_threshold(tmp_path):
     ref = m.get_params()
     got = {k.replace('|', '/'): v for k, v in np.load(out).items()}
     worst = max(float(np.abs(got[k] - ref[k]).max()) for k in ref)
-    assert worst <= 2e-6, worst
+    assert worst <= 5e-6, worst          # (two Adam steps on gradients summed in another order: 1-2.5e-6 seen; a mispaired collective gives 1e-2)
 
 
 # ------------------------------------------------------------------------------------------ fixtures of the big configurations
