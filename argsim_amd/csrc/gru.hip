@@ -872,7 +872,9 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     int team, wk;
     if (T == 4 && PIPE)      { team = wave & 3; wk = wave >> 2; }                                              // one SIMD
     else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }    // a SIMD pair
-    else                     { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
+    else if (PIPE)           { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
+    else                     { team = (wave >> 2) & 1; wk = (wave & 3) + 4 * (wave >> 3); }                   // all four SIMDs: a team whose partner has run out of steps
+                                                                                                               // (ragged batches) has the whole CU: RAGGED 256 x 64 10.76 -> 10.54 ms, FULL 16.50 -> 16.45
     const int n = lane & 15, kh = lane >> 4;
     const TeamMap tm = team_map(a, RB);
     const int cid = tm.cid, ht = tm.ht;
