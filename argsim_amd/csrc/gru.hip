@@ -870,9 +870,11 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
     // addresser; the mapping per form is the best of {one SIMD, a SIMD pair, all four} measured in-process
     // (gpurun_out/ab16.log, scripts/ab_classes.py).
     int team, wk;
-    if (T == 4 && PIPE)      { team = wave & 3; wk = wave >> 2; }                                              // one SIMD
-    else if (T == 4)         { team = (wave & 2) + ((wave >> 2) & 1); wk = (wave & 1) * 2 + (wave >> 3); }    // a SIMD pair
-    else if (PIPE)           { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
+    // (CMP = the compact layout, i.e. a ragged batch: teams run out of steps at different times and the ones still running should
+    //  have every SIMD -- the pipelined forms at 1024 x 64 RAGGED: 32.97 -> 30.37 ms with all four, FULL 59.06 -> 59.88)
+    if (T == 4 && PIPE && !CMP) { team = wave & 3; wk = wave >> 2; }                                           // one SIMD
+    else if (T == 4)         { team = wave >> 2; wk = wave & 3; }                                              // all four SIMDs (RAGGED 10.56 -> 10.43 ms; FULL unchanged)
+    else if (PIPE && !CMP)   { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
     else                     { team = (wave >> 2) & 1; wk = (wave & 3) + 4 * (wave >> 3); }                   // all four SIMDs: a team whose partner has run out of steps
                                                                                                                // (ragged batches) has the whole CU: RAGGED 256 x 64 10.76 -> 10.54 ms, FULL 16.50 -> 16.45
     const int n = lane & 15, kh = lane >> 4;
@@ -1486,9 +1488,9 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_team_kernel(GruArgs a)
     // addresser; the mapping per form is the best of {one SIMD, a SIMD pair, all four} measured in-process
     // (gpurun_out/ab16.log, scripts/ab_classes.py).
     int team, wk;
-    if (T == 4 && PIPE)      { team = wave & 3; wk = wave >> 2; }                                              // one SIMD
+    if (T == 4 && PIPE && !CMP) { team = wave & 3; wk = wave >> 2; }                                           // one SIMD
     else if (T == 4)         { team = wave >> 2; wk = wave & 3; }                                              // all four SIMDs
-    else if (PIPE)           { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair
+    else if (PIPE && !CMP)   { team = (wave >> 1) & 1; wk = (wave & 1) + 2 * (wave >> 2); }                   // a SIMD pair (CMP: all four, see the forward)
     else                     { team = wave >> 3; wk = wave & 7; }                                              // all four SIMDs
     const int n = lane & 15, kh = lane >> 4;
     const TeamMap tm = team_map(a, RB);
