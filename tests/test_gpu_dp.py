@@ -15,7 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("V,D,R,B,S,steps,tol", [(512, 64, 32, 16, 12, 2, 2e-6),
                                                  # benchmark dims: persistent LDS-weight GRU kernels, split-K weight-gradient
                                                  # GEMMs (float atomics: an element whose gradient is ~eps moves by ~lr)
-                                                 (8192, 512, 128, 128, 32, 1, 5e-5)])
+                                                 (8192, 512, 128, 128, 32, 1, 5e-5),
+                                                 # 100 rows per rank (the reference's batch_train): no team-kernel geometry of its own --
+                                                 # phantom rows, compact layout, table-fed first layers under the bucket hook;
+                                                 # the single process runs 200 rows on 256 slots
+                                                 (1024, 512, 64, 200, 24, 2, 5e-5)])
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path, V, D, R, B, S, steps, tol):
     from argsim_amd.model import VAE
     rng = np.random.default_rng(11)
