@@ -8,7 +8,9 @@ key = sys.argv[1]
 B, S = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 64)
 m = VAE('train', seed=0, dtype=os.environ.get('DTYPE', 'f32'), dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 m.step = 20000
-ids = torch.as_tensor(synth.batch(B, S, 8192, ragged=bool(os.environ.get('RAGGED')), seed=0)).cuda()
+_np = synth.batch(B, S, 8192, ragged=bool(os.environ.get('RAGGED')), seed=0, len_median=float(os.environ.get('LEN_MEDIAN', '24')), len_sigma=float(os.environ.get('LEN_SIGMA', '0.5')))
+print('fill %.3f' % (float((_np != 1).sum()) / _np.size), flush=True)
+ids = torch.as_tensor(_np).cuda()
 for i in range(5): m.train_step(ids, ids, seed=i)
 torch.cuda.synchronize()
 NSTEP = int(os.environ.get('NSTEP', '15'))
