@@ -491,7 +491,9 @@ static void launch_variant(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs&
     }
     static const char* db_env = getenv("AVAE_F32_DB");
     if constexpr (WM == 2 && WN == 2) {
-        const bool use_db = db_env ? atoi(db_env) != 0 && !g.A2 : (!g.A2 && g.split_k <= 1 && g.dyn_kind != 1 && tiles > 768 && tiles <= 1024);
+        // (a device-side row count: where the host expects more than one round of the 768 single-stage slots to be real)
+        const int eff_tiles = (g.dyn_kind == 1 && g.dyn_expect > 0) ? std::min(tiles, ((g.dyn_expect + BM - 1) / BM) * ((g.N + BN - 1) / BN)) : (g.dyn_kind == 1 ? 0 : tiles);
+        const bool use_db = db_env ? atoi(db_env) != 0 && !g.A2 : (!g.A2 && g.split_k <= 1 && eff_tiles > 768 && tiles <= 1024);
         if (use_db) {
             if (fast) {
                 if (!a_mc && !b_nc)      hipLaunchKernelGGL((gemm_f32_kernel<false, false, WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, g);

@@ -23,6 +23,7 @@ struct GemmArgs {
     int accumulate;      // C += ...
     int split_k;
     const int* dyn; int dyn_kind;
+    int dyn_expect;      // dyn_kind 1: the count the host expects (an earlier call's; 0 = unknown) -- launch shaping only, never correctness
     int thin;            // 1: 32x128 block tiles (thin row panels) instead of 128x128; 2: 64x64; 3: skinny form (32x32 per workgroup, K split over its waves)
     // optional second problem of identical shape, layout and scalars, run by the same launch (grid.y = 2): two
     // weight-gradient GEMMs over the same rows then share ONE round of workgroups at half the K split (half the

@@ -51,6 +51,7 @@ struct avae_ctx {
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
     int skinny = 1;       // a few rows (latent block, one-step top layer; backward: remainder rows, small products): one 32x32 tile per workgroup,
                           // K split over its waves (gemm_f32.hip); 0: the tiled forms
+    const int* expect_ptr[2] = {nullptr, nullptr}; int expect_val[2] = {0, 0};      // (dyn_expected)
     int rows_form = 0;    // one-shot: the next gemm() call's rows are the batch rows -- skinny form whatever the batch size (see gemm)
     int compact = 2;      // encoder activations stored over the REAL rows only (row_map / GruArgs::rowmap): padded rows of a ragged batch cost nothing in the
                           // encoder's GEMMs.  0 off, 1 on, 2 auto: on where the share of real positions the previous calls reported is below 0.85 (fill_hint)
@@ -313,6 +314,13 @@ int grow_bf16(avae_ctx* h, unsigned short** buf, size_t* cap, size_t need)
     return 0;
 }
 
+// what the host expects a device-side row count to be (the compact layout's counts: an earlier call's fill, build_compact); 0 = unknown
+static int dyn_expected(const avae_ctx* h, const int* dyn, int dyn_kind)
+{
+    if (dyn_kind != 1 || !dyn) return 0;
+    for (int i = 0; i < 2; ++i) if (dyn == h->expect_ptr[i]) return h->expect_val[i];
+    return 0;
+}
 // second problem of a pair (same shape, layout, scalars): see GemmArgs in kernels.h
 struct Pair { const float* A; const float* B; float* C; const float* bias; };
 
@@ -324,7 +332,7 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
         AV_TRY(gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, split_k, dyn, dyn_kind, thin));
         return gemm_raw(h, a_mc, b_nc, pair->A, lda, pair->B, ldb, pair->C, ldc, M, N, K, alpha, pair->bias, accumulate, split_k, dyn, dyn_kind, thin);
     }
-    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, thin,
+    GemmArgs g{A, Bm, C, bias, M, N, K, lda, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, dyn_expected(h, dyn, dyn_kind), thin,
                pair ? pair->A : nullptr, pair ? pair->B : nullptr, pair ? pair->C : nullptr, pair ? pair->bias : nullptr};
     Timed t(h, 0, 2.0 * M * N * K * (pair ? 2 : 1), dyn, dyn_kind == 1 ? M : (dyn_kind == 2 ? K : 0));
     if (h->cfg.compute_dtype == 1 && h->bf16_direct) {
@@ -357,7 +365,7 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
 int gemm_bf16_pre(avae_ctx* h, const unsigned short* A16, int lda16, bool a_mc, const float* Bm, int ldb, bool b_nc, float* C, int ldc,
                   int M, int N, int K, float alpha, int accumulate, int split_k, const int* dyn, int dyn_kind, const float* bias = nullptr)
 {
-    GemmArgs g{nullptr, Bm, C, bias, M, N, K, lda16, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, 0, nullptr, nullptr, nullptr, nullptr};
+    GemmArgs g{nullptr, Bm, C, bias, M, N, K, lda16, ldb, ldc, alpha, accumulate, split_k, dyn, dyn_kind, 0, 0, nullptr, nullptr, nullptr, nullptr};
     Timed t(h, 0, 2.0 * M * N * K, dyn, dyn_kind == 1 ? M : (dyn_kind == 2 ? K : 0));
     const int Kp = (K + 7) & ~7;
     const unsigned short* Ap = A16; int lda_p = lda16;
@@ -380,7 +388,7 @@ int gemm_tn16(avae_ctx* h, const unsigned short* A16, const float* A32, int lda,
               float* C, int ldc, int M, int N, int K, float alpha, const int* dynk)
 {
     const int s = grad_split(M, N, K);
-    GemmArgs g{nullptr, nullptr, C, nullptr, M, N, K, lda, ldb, ldc, alpha, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, 0, nullptr, nullptr, nullptr, nullptr};
+    GemmArgs g{nullptr, nullptr, C, nullptr, M, N, K, lda, ldb, ldc, alpha, s > 1 ? 0 : 1, s, dynk, dynk ? 2 : 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
     Timed t(h, 0, 2.0 * M * N * K, dynk, dynk ? K : 0);
     int la = lda, lb = ldb;
     if (!A16) {
@@ -602,16 +610,17 @@ static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
 int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
 {
     w.compact = false; w.compact_d = false;
+    h->expect_ptr[0] = h->expect_ptr[1] = nullptr;
     if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B, B)) return 0;
     const bool phantom = w.Bx != B;        // a batch without a team geometry of its own: the compact layout is what lets it run the team kernels at all
     if (phantom && !(w.ord_ok[0] && (w.ord_ok[1] || !top_one_step(h)))) return 0;
     if (h->compact == 2 && !phantom) {
         // auto: the layout pays where a good share of the padded positions is padding; on FULL batches the static row counts shape
-        // the GEMM launches better (16.8 vs 17.3 ms at configs[1]).  The hint is an EARLIER call's count (no synchronisation).
+        // the GEMM launches a little better (16.48 vs 16.71 ms at configs[1]; break-even at a fill of 0.93).  The hint is an EARLIER call's count (no synchronisation).
         // (both words in ONE 8-byte load: the copy that lands them is 8 bytes, so a pair is never half of one call and half of another)
         const uint64_t pair = h->hint_host ? *reinterpret_cast<const volatile uint64_t*>(h->hint_host) : 0xffffffffull;
         const int32_t real = (int32_t)(uint32_t)(pair & 0xffffffffull), rows = (int32_t)(uint32_t)(pair >> 32);
-        if (real < 0 || rows <= 0 || (double)real >= 0.85 * (double)rows) return 0;
+        if (real < 0 || rows <= 0 || (double)real >= 0.92 * (double)rows) return 0;
     }
     const int D = h->cfg.dim_emb;
     for (int njobs = 1; njobs <= 2; ++njobs) {
@@ -623,6 +632,13 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
     }
     AV_CHECK(row_map(h->stream, w.lens_src, 0, Ss, B, w.map_src, w.nact_src, w.nsrc));
     w.compact = true;
+    {   // the fill the host last saw, scaled to this call's rows: shapes the launches of the GEMMs over the compact rows
+        const uint64_t pair = h->hint_host ? *reinterpret_cast<const volatile uint64_t*>(h->hint_host) : 0xffffffffull;
+        const int32_t real = (int32_t)(uint32_t)(pair & 0xffffffffull), rows = (int32_t)(uint32_t)(pair >> 32);
+        const double fill = (real > 0 && rows > 0) ? std::min(1.0, (double)real / (double)rows) : 0.0;
+        h->expect_ptr[0] = w.nsrc; h->expect_val[0] = (int)(fill * Ss * B);
+        h->expect_ptr[1] = w.ntgt; h->expect_val[1] = (int)(fill * T * B);
+    }
     // the decoder stack the same way (training / evaluation calls: T > 1): a row's steps end one behind its last non-eos target id
     if (T < 2 || !use_table(h, T * B, B) || h->compact == 3) return 0;      // (3: the encoder alone, for measurements)
     if (phantom && !w.ord_ok[2]) return 0;

@@ -11,6 +11,8 @@ m.step = 20000
 BB, SS = int(os.environ.get('B', '256')), int(os.environ.get('S', '64'))
 ids = torch.as_tensor(synth.batch(BB, SS, 8192, ragged=bool(os.environ.get('RAGGED')), seed=0)).cuda()
 print('tokens incl. eos:', int((ids != 1).sum()) + BB)
+for kv in os.environ.get('OPTS', '').split(','):
+    if kv: m.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 for i in range(3): m.train_step(ids, ids, seed=i)
 m.set_option('timing', 1)
 m.train_step(ids, ids, seed=9)
