@@ -8,7 +8,11 @@ l = lib.load()
 cfg = lib.AvaeConfig(32, 16, 8, 1, 1e-4, 1e-3, 2, 1, 0, 0, 1.0, 0.0, 0)
 h = C.c_void_p(); assert l.avae_create(C.byref(cfg), 0, C.byref(h)) == 0
 dev = torch.device('cuda', 0)
-shapes = [('out affine NN', 0, 1, 16384, 512, 512), ('out affine tail', 0, 1, 256, 512, 512), ('dhc NT', 0, 0, 16384, 512, 512),
+if os.environ.get('RAGGED_SHAPES'):       # the compact layout's row count on the RAGGED set (7.4 k real positions of 16.4 k)
+    shapes = [('dec gi NT', 0, 0, 7424, 1536, 512), ('dec dx NN', 0, 1, 7424, 512, 1536), ('enc gi L2 NT', 0, 0, 7168, 3072, 1024),
+              ('enc dx NN', 0, 1, 7168, 1024, 3072), ('out affine NN', 0, 1, 7424, 512, 512), ('logits NT', 0, 0, 7424, 8192, 512)]
+else:
+  shapes = [('out affine NN', 0, 1, 16384, 512, 512), ('out affine tail', 0, 1, 256, 512, 512), ('dhc NT', 0, 0, 16384, 512, 512),
           ('table dec NT U=3328', 0, 0, 3328, 1536, 512), ('table enc NT U=3584', 0, 0, 3584, 3072, 512),
           ('logits tail NT', 0, 0, 256, 8192, 512), ('dec tail NT', 0, 0, 256, 1536, 512)]
 for name, a_mc, b_nc, M, N, K in shapes:
