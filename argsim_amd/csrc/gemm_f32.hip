@@ -410,19 +410,29 @@ __global__ __launch_bounds__(512) void gemm_f32_skinny_kernel(GemmArgs g)
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // lane (l31, h) feeds k = kk + 4 h + {0..3} of an 8-wide step: A[row l31][k] and B[k][col l31] (any pairing of k indices is a
     // valid contraction order as long as both operands use the same one)
-    for (int kk = k0; kk < k1; kk += 8) {
-        const int k = kk + 4 * h;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < k1) {                                               // (K and the chunks are multiples of 4: a whole float4 or nothing)
-            a = *reinterpret_cast<const float4*>(ap + k);
-            if constexpr (B_NC) {
-                b.x = bp[(size_t)k * g.ldb]; b.y = bp[(size_t)(k + 1) * g.ldb]; b.z = bp[(size_t)(k + 2) * g.ldb]; b.w = bp[(size_t)(k + 3) * g.ldb];
-            } else b = *reinterpret_cast<const float4*>(bp + k);
+    // four 8-wide steps per pass: their eight operand loads are issued together (one L2 round trip per 32 k instead of one per 8),
+    // the MFMAs follow in the k order of the plain loop -- the same sums, bit for bit
+    for (int kk = k0; kk < k1; kk += 32) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kk + 8 * u + 4 * h;
+            a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < k1) {                                           // (K and the chunks are multiples of 4: a whole float4 or nothing)
+                a[u] = *reinterpret_cast<const float4*>(ap + k);
+                if constexpr (B_NC) {
+                    b[u].x = bp[(size_t)k * g.ldb]; b[u].y = bp[(size_t)(k + 1) * g.ldb]; b[u].z = bp[(size_t)(k + 2) * g.ldb]; b[u].w = bp[(size_t)(k + 3) * g.ldb];
+                } else b[u] = *reinterpret_cast<const float4*>(bp + k);
+            }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (kk + 8 * u >= k1) break;                            // (uniform: a step wholly behind the chunk adds nothing -- skipped so that the sums keep the plain loop's order)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
     }
     if (wave > 0) {
 #pragma unroll

@@ -112,6 +112,7 @@ struct GruArgs {
     int force_slow;       // 1: never use the same-XCD L2 fast path
     int sv16;             // 1 (bf16 team kernels, forward AND backward of a layer): the saved gates r, u, n, hn are stored as bf16
     int bf16;             // 1 (compute_dtype 1): the team kernels round both operands of the recurrent product to bf16
+    int bwd_rs;           // 1: the backward runs the reduce-scatter team kernel (gru_rs.hip) where the team geometry applies and xbuf holds its ring
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };
 hipError_t gru_forward(hipStream_t st, const GruArgs& a, bool persistent);
@@ -123,11 +124,15 @@ bool gru_team_shape(const GruArgs& a, bool fwd, bool persistent, int* T, int* cp
 int gru_team_batch(int B);        // smallest row count >= B (within 256) the team kernels have a geometry for with one job and with two; 0: none
 bool gru_backward_uses_team(const GruArgs& a, bool persistent);     // true: the launch runs the LDS-weight team kernels (dgi16 / dgh16 honoured in bf16 mode)
 bool gru_dim_supported(int D);
+// reduce-scatter form of the backward team kernels (gru_rs.hip): floats of exchange scratch it needs for njobs jobs over `rows` slots
+size_t gru_bwd_rs_xbuf_floats(int njobs, int rows);
+hipError_t gru_bwd_rs_launch(hipStream_t st, const GruArgs& a, int T, int C, bool pipe, bool cmp);
+bool gru_backward_uses_rs(const GruArgs& a, bool persistent);     // true: the launch runs the reduce-scatter form
 // one GRU step from a zero state for B rows (the top encoder layer's backward direction: gru.hip "one step from a zero
 // state"): gi (B, 3D) / bR G16; h -> h_out[b * ldo + j]; sv (B, D, 4) = r, u, n, hn or nullptr
-hipError_t gru_first_step_fwd(hipStream_t st, const float* gi, const float* bR, float* h_out, int ldo, float* sv, int B, int D);
+hipError_t gru_first_step_fwd(hipStream_t st, const float* gi, const float* bR, float* h_out, int ldo, float* sv, int B, int D, const int32_t* lens = nullptr);      // lens: rows of length 0 get h = 0
 // its backward: dh[b * ldd + j] -> dgi, dgh (B, 3D) G16
-hipError_t gru_first_step_bwd(hipStream_t st, const float* dh, int ldd, const float* sv, float* dgi, float* dgh, int B, int D);
+hipError_t gru_first_step_bwd(hipStream_t st, const float* dh, int ldd, const float* sv, float* dgi, float* dgh, int B, int D, const int32_t* lens = nullptr);
 bool gru_diag_build();     // true: built with -DAVAE_DIAG (ablation / stamp instantiations present)
 
 // ---------------------------------------------------------------- small kernels (ops.hip)
@@ -244,8 +249,9 @@ int decode_workgroups();                            // CU count of the current d
 // natural <-> G16 row permutation of a (3D, cols) matrix (cols = 1 for biases)
 hipError_t g16_permute(hipStream_t st, float* dst, const float* src, int D, int cols, bool to_g16);
 
-// losses[0..2] = loss_gen, loss_kld, loss from accumulators
-hipError_t finalize_losses(hipStream_t st, float* losses, const float* acc, const int32_t* n_dev,
-                           float n_override, float inv_br, float anneal);
+// losses[0..2] = loss_gen, loss_kld, loss (model.py:181-185) from the per-token CE (n = min(n_max, *n_dev) entries) and the
+// per-element KL terms (nk entries, each floored at free_bits), summed in a fixed order: bit-reproducible
+hipError_t finalize_losses(hipStream_t st, float* losses, const float* loss_samp, const int32_t* n_dev, int n_max,
+                           const float* kld, int nk, float free_bits, float inv_br, float anneal);
 
 }  // namespace avae

@@ -64,6 +64,8 @@ struct avae_ctx {
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
+    int bwd_rs = 2;       // fp32 BPTT team kernels in the reduce-scatter form (gru_rs.hip: own gate columns x resident R slice, partial dH summed through the
+                          // exchange): 0 never, 1 wherever the geometry allows, 2 auto -- where few rows are alive per step (rs_pick)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
     // offsets
     int64_t oE = 0, oKout = 0, oBout = 0, oWmu = 0, oBmu = 0, oWlv = 0, oBlv = 0, oWex = 0, oBex = 0;
@@ -249,6 +251,7 @@ void layout(avae_ctx* h, Bump& b, Ws& w, int B, int Ss, int St, bool train)
         w.Bx = bx > 0 ? bx : B;
         const size_t rows = std::max<size_t>(2 * Ss, T) * (size_t)w.Bx;
         w.xbuf_floats = rows * D * (train ? 3 : 1);
+        if (train && D == 512 && h->bwd_rs) w.xbuf_floats = std::max(w.xbuf_floats, gru_bwd_rs_xbuf_floats(2, w.Bx));      // (the reduce-scatter BPTT's ring, gru_rs.hip)
         w.xbuf = b.take<float>(w.xbuf_floats);
     }
     w.map_src = b.take<int32_t>(rs); w.nact_src = b.take<int32_t>(Ss + 1); w.nsrc = b.take<int32_t>(4); w.compact = false;
@@ -538,6 +541,23 @@ Sched schedule(const avae_ctx* h)
 // direction alone.  Same values as the full form (option enc_top1 = 0), a sixth of the encoder's work not executed.
 static bool top_one_step(const avae_ctx* h) { return h->enc_top1 && h->cfg.rnn_layers >= 2; }
 
+// The share of the padded source positions that are real, as the host last saw it (the asynchronous hint of build_row_orders;
+// 1.0 while nothing has arrived).  Shapes launches only, never a value.
+static double expected_fill(const avae_ctx* h)
+{
+    const uint64_t pair = h->hint_host ? *reinterpret_cast<const volatile uint64_t*>(h->hint_host) : 0xffffffffull;
+    const int32_t real = (int32_t)(uint32_t)(pair & 0xffffffffull), rows = (int32_t)(uint32_t)(pair >> 32);
+    return (real > 0 && rows > 0) ? std::min(1.0, (double)real / (double)rows) : 1.0;
+}
+// Which BPTT team kernel a launch of njobs jobs over B rows takes (option bwd_rs = 2): the reduce-scatter form stores 64 KB per live
+// row and step where the other form stores 6 KB, so it pays where few rows are alive -- measured break-even at about 220 live
+// row-chains per step (RAGGED 256 x 64 at fill 0.44: a tie; batch 100 x 512 ragged: -8 % of the step; FULL 256 x 64: +5 %).
+static int rs_pick(const avae_ctx* h, int njobs, int B)
+{
+    if (h->bwd_rs != 2) return h->bwd_rs;
+    return expected_fill(h) * B * njobs < 200.0 ? 1 : 0;
+}
+
 // -------------------------------------------------------------------------------- forward pieces
 // GRU launch arguments common to every call site
 static void gru_common(avae_ctx* h, const Ws& w, GruArgs& a, int njobs, int S, int B, int ldg, int ldh, const int32_t* lens)
@@ -548,7 +568,7 @@ static void gru_common(avae_ctx* h, const Ws& w, GruArgs& a, int njobs, int S, i
     gru_geometry(D, njobs, B, &a.G, &a.rows_per_group);
     a.p_begin = 0; a.p_end = S; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow;
     a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item;
-    a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+    a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16); a.bwd_rs = h->bwd_rs != 0;
 }
 // Row orders of this call (one launch, after prep_ids has the lengths): for every GRU launch shape of the step whose team
 // kernels can skip padding, the batch rows sorted by length and dealt over the workgroups.  with_dec: the decoder runs too.
@@ -682,7 +702,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         a.Bx = w.bx_enc();
         gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16); a.bwd_rs = h->bwd_rs != 0;
         // table-fed layer: the team kernels read gi straight out of the per-id projection through a row index per token;
         // the other kernel forms get a per-token copy
         const bool table0 = i == 0 && table, indirect = table0 && gru_forward_uses_team(a, h->persistent != 0);
@@ -724,7 +744,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
     else
     AV_CHECK(pick_last(h->stream, w.hpick, w.e_hs[L - 1], w.lens_src, B, 2 * D, cmap));
     if (top_one_step(h))      // (the pick copied the never-written backward half of the top layer's rows: overwritten here)
-        AV_CHECK(gru_first_step_fwd(h->stream, w.gib, h->P + h->enc[L - 1].bR + 3 * D, w.hpick + D, 2 * D, save ? w.svb : nullptr, B, D));
+        AV_CHECK(gru_first_step_fwd(h->stream, w.gib, h->P + h->enc[L - 1].bR + 3 * D, w.hpick + D, 2 * D, save ? w.svb : nullptr, B, D, w.lens_src));
     return 0;
 }
 
@@ -735,7 +755,7 @@ int run_latent(avae_ctx* h, Ws& w, int B, bool train, uint64_t seed, const float
         const Pair lv{w.hpick, h->P + h->oWlv, w.lv, h->P + h->oBlv};
         AV_TRY(gemm_raw(h, false, true, w.hpick, 2 * D, h->P + h->oWmu, R, w.mu, R, B, R, 2 * D, 1.f, h->P + h->oBmu, 0, 1, nullptr, 0, h->skinny ? 3 : (B <= 512 ? 1 : 0), &lv));      // (rows = the batch rows: the skinny form for every batch size)
     }
-    AV_CHECK(latent_fwd(h->stream, w.mu, w.lv, eps, w.eps, w.z, w.kld, B * R, train ? 1 : 0, seed, h->cfg.free_bits, h->acc + 1));
+    AV_CHECK(latent_fwd(h->stream, w.mu, w.lv, eps, w.eps, w.z, w.kld, B * R, train ? 1 : 0, seed, h->cfg.free_bits, nullptr));      // (KL scalar: finalize_losses, fixed order)
     return 0;
 }
 
@@ -768,7 +788,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         a.Bx = compact ? w.Bx : 0;
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16); a.bwd_rs = h->bwd_rs != 0;
         GruJob& j = a.job[0];
         const bool table0 = i == 0 && ids0, indirect = table0 && gru_forward_uses_team(a, h->persistent != 0);
         if (indirect) AV_CHECK(rank_rows(h->stream, w.tokrow_tgt, ids0, id_groups_rank(w.grp_tgt, rt, h->cfg.dim_tgt), rt, h->cfg.dim_tgt));
@@ -804,7 +824,7 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     p.src = src; p.tgt = tgt; p.B = B; p.Ss = Ss; p.St = St; p.eos = h->cfg.eos; p.bos = h->cfg.bos;
     p.train = train ? 1 : 0; p.keepwd = sc.keepwd; p.seed = seed; p.keep_mask = keep_mask;
     p.src_tm = w.src_tm; p.lens_src = w.lens_src; p.lens_tgt = w.lens_tgt; p.lead = w.lead; p.gold = w.gold;
-    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4; p.zero2 = h->acc;
+    p.rank = w.rank; p.cidx = w.cidx; p.ntok = w.ntok; p.chunk_counts = w.ntok + 4; p.zero2 = nullptr;
     AV_CHECK(prep_ids(h->stream, p));
     AV_TRY(build_row_orders(h, w, B, Ss, T, true));
     AV_TRY(build_compact(h, w, B, Ss, T, train));
@@ -827,10 +847,10 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
         AV_TRY(grow_bf16(h, &h->bfP, &h->bfP_cap, (size_t)rt * V));
         c.grad16 = h->bfP;
     }
-    c.loss_samp = w.loss_samp; c.errt_samp = w.errt_samp; c.pred = w.pred; c.loss_acc = h->acc;
+    c.loss_samp = w.loss_samp; c.errt_samp = w.errt_samp; c.pred = w.pred; c.loss_acc = nullptr;      // (the scalar is summed from loss_samp in a fixed order: finalize_losses)
     AV_CHECK(softmax_ce(h->stream, c));
     float beta = h->cfg.kl_beta;
-    AV_CHECK(finalize_losses(h->stream, h->losses, h->acc, w.ntok, 0.f, 1.f / ((float)B * R), sc.anneal * beta));
+    AV_CHECK(finalize_losses(h->stream, h->losses, w.loss_samp, w.ntok, rt, w.kld, B * R, h->cfg.free_bits, 1.f / ((float)B * R), sc.anneal * beta));
     return 0;
 }
 
@@ -899,7 +919,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         a.njobs = 1; a.S = T; a.B = B; a.D = D; a.ldg = 3 * D; a.ldh = D; a.lens = nullptr;
         a.Bx = w.bx_dec();
         gru_geometry(D, 1, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = T; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16); a.bwd_rs = h->bwd_rs != 0;
         GruJob& j = a.job[0];
         j.R = P + p.R; j.sv = w.d_sv[i]; j.hp = w.d_hp[i]; j.reverse = 0;
         j.dh_out = w.dhd[cur]; j.dgi = w.dgi_d; j.dgh = w.dgh_d;
@@ -918,6 +938,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         attach_order(h, w, a, false, 2);
         a.rowmap = dmap;
         if (dmap && i == 0) j.dgi_by_pos = 1;       // (table-fed: its gate gradients are summed by token id)
+        a.bwd_rs = rs_pick(h, 1, B);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -986,7 +1007,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         if (top1) {
             // backward direction of the top layer: BPTT of its one live step (dH = the pick's gradient, nothing carried),
             // bias gradients = column sums over the B rows; dR of this direction stays exactly zero (h_prev = 0)
-            AV_CHECK(gru_first_step_bwd(st, w.dhpick + D, 2 * D, w.svb, w.dgib, w.dghb, B, D));
+            AV_CHECK(gru_first_step_bwd(st, w.dhpick + D, 2 * D, w.svb, w.dgib, w.dghb, B, D, w.lens_src));
             AV_CHECK(colsum(st, w.dgib, B, 3 * D, 3 * D, G + p.bW + 3 * D, nullptr));
             AV_CHECK(colsum(st, w.dghb, B, 3 * D, 3 * D, G + p.bR + 3 * D, nullptr));
         }
@@ -994,7 +1015,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         a.njobs = top1 ? 1 : 2; a.S = Ss; a.B = B; a.D = D; a.ldg = 6 * D; a.ldh = 2 * D; a.lens = w.lens_src;
         a.Bx = w.bx_enc();
         gru_geometry(D, a.njobs, B, &a.G, &a.rows_per_group);
-        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16);
+        a.p_begin = 0; a.p_end = Ss; a.counters = h->counters; a.err = h->errw; a.ablate = h->gru_ablate; a.force_slow = h->gru_force_slow; a.bf16 = h->cfg.compute_dtype == 1 && h->gru_bf16; a.stagger = h->gru_stagger; a.item_pipeline = h->gru_item; a.xbuf = w.xbuf; a.xbuf_floats = w.xbuf_floats; a.stamps = reinterpret_cast<unsigned long long*>(h->errw + 16); a.bwd_rs = h->bwd_rs != 0;
         for (int d = 0; d < a.njobs; ++d) {
             GruJob& j = a.job[d];
             j.R = P + p.R + (int64_t)d * 3 * D * D; j.sv = w.e_sv[d][i]; j.hp = w.e_hp[d][i]; j.reverse = d;
@@ -1012,6 +1033,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         attach_order(h, w, a, false, top1 ? 1 : 0);
         a.rowmap = cmap;
         if (cmap && i == 0) for (int d = 0; d < a.njobs; ++d) a.job[d].dgi_by_pos = 1;      // (table-fed: its gate gradients are summed by token id)
+        a.bwd_rs = rs_pick(h, a.njobs, B);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -1306,6 +1328,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_stagger")) { h->gru_stagger = value; return 0; }
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
+    if (!strcmp(key, "bwd_rs")) { h->bwd_rs = value; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
     if (!strcmp(key, "bf16_sv")) { h->bf16_sv = value != 0; return 0; }
@@ -1375,6 +1398,23 @@ int avae_debug_present_ids(avae_handle h, int32_t out[2])
     out[0] = out[1] = -1;
     if (h->cnt_src) AV_CHECK(hipMemcpy(&out[0], h->cnt_src, sizeof(int), hipMemcpyDeviceToHost));
     if (h->cnt_tgt) AV_CHECK(hipMemcpy(&out[1], h->cnt_tgt, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+// test hook: the per-token cross-entropy (model.py:180 loss_gen_samp) of the LAST avae_forward_backward / avae_train_step -- the
+// TRAIN forward, word dropout and the latent draw live -- copied to out (device memory, max_n floats); *n_out = its token count.
+// (The workspace layout is a pure function of the call geometry, so the array is found again without keeping a pointer.)
+int avae_debug_train_ce(avae_handle h, float* out, int32_t max_n, int32_t* n_out)
+{
+    if (!h || !out || !n_out) return 1;
+    if (h->B < 1) return fail(h, "avae_debug_train_ce: no training forward has run on this handle");
+    Ws w;
+    AV_TRY(get_ws(h, w, h->B, h->Ss, h->St, true));
+    int n = 0;
+    AV_CHECK(hipMemcpyAsync(&n, w.ntok, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AV_CHECK(hipStreamSynchronize(h->stream));
+    n = std::min(n, (int)max_n);
+    AV_CHECK(hipMemcpyAsync(out, w.loss_samp, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    *n_out = n;
     return 0;
 }
 // diagnostic: per-launch (class, ms, FLOPs) triples of the stamps recorded since timing was switched on, in launch

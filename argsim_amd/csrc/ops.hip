@@ -621,9 +621,13 @@ __global__ __launch_bounds__(256) void pick_last_kernel(float* __restrict__ h, c
 {
     const int b = blockIdx.x;
     int t = max(lens[b] - 1, 0);
-    const size_t row = map ? (size_t)max(map[(size_t)t * B + b], 0) : (size_t)t * B + b;
-    const float4* s = reinterpret_cast<const float4*>(hs + row * W);
+    // A row without a single non-eos id (len 0; compact layout: no place among the real positions, map = -1): the reference is
+    // undefined there (gather_nd at index -1, model.py:135).  The build picks zeros and passes no gradient, in every layout --
+    // never another sentence's row
+    const long long mrow = map ? (long long)map[(size_t)t * B + b] : (long long)t * B + b;
     float4* d = reinterpret_cast<float4*>(h + (size_t)b * W);
+    if (mrow < 0 || lens[b] <= 0) { for (int c = threadIdx.x; c < W / 4; c += blockDim.x) d[c] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const float4* s = reinterpret_cast<const float4*>(hs + (size_t)mrow * W);
     for (int c = threadIdx.x; c < W / 4; c += blockDim.x) d[c] = s[c];
 }
 hipError_t pick_last(hipStream_t st, float* h, const float* hs, const int32_t* lens, int B, int W, const int32_t* map)
@@ -636,9 +640,10 @@ __global__ __launch_bounds__(256) void pick_last16_kernel(float* __restrict__ h,
 {
     const int b = blockIdx.x;
     const int t = max(lens[b] - 1, 0);
-    const size_t row = map ? (size_t)max(map[(size_t)t * B + b], 0) : (size_t)t * B + b;
-    const uint2* s = reinterpret_cast<const uint2*>(hs + row * W);      // four bf16 per access
+    const long long mrow = map ? (long long)map[(size_t)t * B + b] : (long long)t * B + b;      // (-1: see pick_last_kernel)
     float4* d = reinterpret_cast<float4*>(h + (size_t)b * W);
+    if (mrow < 0 || lens[b] <= 0) { for (int c = threadIdx.x; c < W / 4; c += blockDim.x) d[c] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const uint2* s = reinterpret_cast<const uint2*>(hs + (size_t)mrow * W);      // four bf16 per access
     for (int c = threadIdx.x; c < W / 4; c += blockDim.x) {
         const uint2 v = s[c];
         d[c] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
@@ -654,8 +659,9 @@ __global__ __launch_bounds__(256) void pick_last_add_kernel(float* __restrict__ 
 {
     const int b = blockIdx.x;
     const int t = max(lens[b] - 1, 0);
-    const size_t row = map ? (size_t)max(map[(size_t)t * B + b], 0) : (size_t)t * B + b;
-    float4* dst = reinterpret_cast<float4*>(dhs + row * W);
+    const long long mrow = map ? (long long)map[(size_t)t * B + b] : (long long)t * B + b;
+    if (mrow < 0 || lens[b] <= 0) return;                   // (a row without a real position: nothing to add to, see pick_last_kernel)
+    float4* dst = reinterpret_cast<float4*>(dhs + (size_t)mrow * W);
     const float4* s = reinterpret_cast<const float4*>(d + (size_t)b * W);
     for (int c = threadIdx.x; c < W / 4; c += blockDim.x) {
         float4 v = dst[c]; const float4 a = s[c];
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(256) void pick_last_bwd_kernel(float* __restrict__ 
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
         int s = row / B, b = row - s * B;
         float4* d = reinterpret_cast<float4*>(dhs + (size_t)row * W);
-        if (s == max(lens[b] - 1, 0)) {
+        if (s == lens[b] - 1) {       // (a row of length 0 has no such position: see pick_last_kernel)
             const float4* src = reinterpret_cast<const float4*>(dh + (size_t)b * W);
             for (int c = lane; c < W / 4; c += 64) d[c] = src[c];
         } else {
@@ -1054,17 +1060,33 @@ hipError_t g16_permute(hipStream_t st, float* dst, const float* src, int D, int 
     return hipGetLastError();
 }
 
-__global__ void finalize_losses_kernel(float* losses, const float* acc, const int32_t* n_dev, float inv_br, float anneal)
+// The three scalars of model.py:181-185 from the per-sample arrays, summed in a FIXED order (thread i takes elements i, i + 1024,
+// ...; then a tree over the block): the same inputs give the same bits run after run -- no float atomics (SURVEY section 5 asks
+// for a same-seed => bit-identical-loss determinism test).  loss_samp (n tokens) and kld (nk = B R elements) are written by
+// softmax_ce / latent_fwd anyway; 16 640 + 32 768 floats at configs[1], one 1024-thread block, ~6 us.
+__global__ __launch_bounds__(1024) void finalize_losses_kernel(float* losses, const float* __restrict__ loss_samp, const int32_t* n_dev, int n_max,
+                                                               const float* __restrict__ kld, int nk, float free_bits, float inv_br, float anneal)
 {
-    float n = (float)max(*n_dev, 1);
-    float gen = acc[0] / n, kld = acc[1] * inv_br;
-    losses[0] = gen; losses[1] = kld; losses[2] = anneal * kld + gen;
+    __shared__ float sh[2][1024];
+    const int tid = threadIdx.x, n = min(n_max, *n_dev);
+    float sg = 0.f, sk = 0.f;
+    for (int i = tid; i < n; i += 1024) sg += loss_samp[i];
+    for (int i = tid; i < nk; i += 1024) sk += fmaxf(kld[i], free_bits);
+    sh[0][tid] = sg; sh[1][tid] = sk;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float gen = sh[0][0] / (float)max(n, 1), kl = sh[1][0] * inv_br;
+        losses[0] = gen; losses[1] = kl; losses[2] = anneal * kl + gen;
+    }
 }
-hipError_t finalize_losses(hipStream_t st, float* losses, const float* acc, const int32_t* n_dev,
-                           float n_override, float inv_br, float anneal)
+hipError_t finalize_losses(hipStream_t st, float* losses, const float* loss_samp, const int32_t* n_dev, int n_max,
+                           const float* kld, int nk, float free_bits, float inv_br, float anneal)
 {
-    (void)n_override;
-    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1), 0, st, losses, acc, n_dev, inv_br, anneal);
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, st, losses, loss_samp, n_dev, n_max, kld, nk, free_bits, inv_br, anneal);
     return hipGetLastError();
 }
 

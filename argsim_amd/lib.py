@@ -54,6 +54,7 @@ SIGNATURES = {
     'avae_debug_gemm_tn16': (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 6 + [C.c_float]),
     'avae_timing_collect': (C.c_int, [_P, C.POINTER(C.c_double)]),
     'avae_debug_timing': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
+    'avae_debug_train_ce': (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     'avae_debug_stamps': (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     'avae_debug_present_ids': (C.c_int, [_P, C.POINTER(C.c_int32)]),
     'avae_debug_team_batch': (C.c_int, [C.c_int32]),

@@ -190,6 +190,16 @@ class VAE:
         self._ck(self._l.avae_debug_present_ids(self._h, out))
         return int(out[0]), int(out[1])
 
+    def train_ce(self, max_n=1 << 22):
+        """per-token cross-entropy (loss_gen_samp, model.py:180) of the last forward_backward / train_step: the TRAIN forward,
+        dropout and the latent draw live (test hook)"""
+        buf = torch.empty(max_n, dtype=torch.float32, device=self.device)
+        n = C.c_int32()
+        self._stream()
+        self._ck(self._l.avae_debug_train_ce(self._h, C.c_void_p(buf.data_ptr()), max_n, C.byref(n)))
+        torch.cuda.synchronize(self.device)
+        return buf[:n.value].cpu().numpy()
+
     def buckets(self):
         out = []
         for i in range(self._l.avae_bucket_count(self._h)):

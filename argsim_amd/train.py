@@ -214,12 +214,18 @@ def main(argv=None):
     if not A.rounds:
         sys.exit("profiling done")
 
-    dp = host_group = None
+    dp = count_group = valid_group = None
     if world > 1:
         import torch.distributed as dist
         from .dist import DataParallel
         dist.init_process_group('nccl')
-        host_group = dist.new_group(backend='gloo')      # host-side scalars (token counts, validation sums): never on the GPU's queue
+        # host-side scalars never go on the GPU's queue.  ONE gloo group PER ISSUING THREAD: gloo pairs collectives by per-group
+        # issue order, the token counts are issued from the prefetch thread and the validation sums from the main thread, and
+        # nothing orders those two threads the same way on every rank (a rank with fewer validation chunks reaches summ's
+        # all-reduce while its prefetch thread has not yet issued the next count) -- on one group an 8-byte all-reduce could be
+        # paired with a 40-byte one
+        count_group = dist.new_group(backend='gloo')     # prefetch thread: with_global_counts
+        valid_group = dist.new_group(backend='gloo')     # main thread: summ
         dp = DataParallel(model)
     if A.ckpt:
         ckpt.restore(model, pform(P.ckpt, A.ckpt))
@@ -229,7 +235,7 @@ def main(argv=None):
     eos = vocab.eos_id()
     batches = batch(T.batch_train, P.train, vocab, A.seed, A.sample, T.max_len, rank, world)
     if dp:      # the global token count rides with the batch (one host-side all-reduce inside the prefetch thread)
-        batches = with_global_counts(batches, eos, host_group)
+        batches = with_global_counts(batches, eos, count_group)
     stream = pipe(pinned(batches), A.prefetch)
     os.makedirs(P.log, exist_ok=True)
     os.makedirs(P.ckpt, exist_ok=True)
@@ -247,7 +253,7 @@ def main(argv=None):
             lg, lk, lo = model.losses()
             dt = time.perf_counter() - t0
             step = model.step
-            errt, vgen, vkld = summ(model, valid, T.batch_valid, rank, world, host_group)      # every rank: its share of the chunks
+            errt, vgen, vkld = summ(model, valid, T.batch_valid, rank, world, valid_group)      # every rank: its share of the chunks
             if rank == 0:
                 rec = dict(step=step, step_errt=errt, step_loss_gen=vgen, step_loss_kld=vkld,
                            train_loss_gen=lg, train_loss_kld=lk, sentences_per_sec=A.valid_every * T.batch_train / dt)

@@ -36,6 +36,9 @@ BIG_CASES = {
     'cfg0':     (dict(dim_tgt=8192, dim_emb=512, dim_rep=1024, rnn_layers=3), 32, 64, 'ragged', {}),
     'cfg4':     (dict(dim_tgt=8192, dim_emb=512, dim_rep=512, rnn_layers=3), 64, 32, 'ragged', dict(kl_beta=0.5, free_bits=0.02)),
     'headline': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 256, 64, 'synth', {}),
+    # round 4: a batch WITHOUT a team-kernel geometry of its own -- 100 rows run in the 128-slot geometry with 28 phantom
+    # rows, the compact layout whatever the fill, table-fed first layers below the vocabulary size (1 200 tokens >= 1 024)
+    'phantom100': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 100, 12, 'ragged', {}),
 }
 
 

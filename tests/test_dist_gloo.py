@@ -250,3 +250,68 @@ def test_host_side_token_counts_and_sharded_validation(tmp_path):
         glob.append(ids)
     one = summ(_EvalStub(), np.concatenate(glob), 5)
     assert np.allclose(got['summ'], one, rtol=1e-6, atol=0)
+
+
+def _two_thread_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    count_group, valid_group = dist.new_group(backend='gloo'), dist.new_group(backend='gloo')      # as train.main creates them
+    import itertools
+    import time
+    from argsim_amd.dist import shard_rows
+    from argsim_amd.train import pipe, summ, with_global_counts
+    rng = np.random.default_rng(9)
+    glob = []
+    for _ in range(40):
+        ids = np.ones((8, 10), np.int32)
+        for b in range(8):
+            n = int(rng.integers(1, 11)); ids[b, :n] = rng.integers(3, 50, n)
+        glob.append(ids)
+    lo, hi = shard_rows(8, rank, world)
+
+    def shards():
+        for g in glob:
+            if rank == 1:
+                time.sleep(0.01)          # one rank's tokeniser is slow: its prefetch thread issues every count late
+            yield g[lo:hi], g[lo:hi]
+    stream = pipe(with_global_counts(shards(), 1, count_group), 2)       # shallow queue: the prefetch thread keeps issuing all the while
+    valid = np.concatenate(glob[:5])
+    got, sums = [], []
+    for block in range(4):
+        got += [n for _, _, n in itertools.islice(stream, 10)]
+        # rank 0 reaches the validation all-reduce at once, rank 1 late; both prefetch threads are mid-stream
+        if rank == 1:
+            time.sleep(0.05)
+        sums.append(summ(_EvalStub(), valid, 5, rank, world, valid_group))
+    want = [float((g != 1).sum() + len(g)) for g in glob]
+    if rank == 0:
+        torch.save({'got': got, 'want': want, 'sums': sums}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_counts_from_the_prefetch_thread_and_validation_sums_interleave(tmp_path):
+    """with_global_counts all-reduces from the prefetch thread, summ from the main thread; on ONE gloo group
+    their per-group issue order could differ between ranks (a rank that reaches summ before its prefetch thread has issued the
+    next count) and an 8-byte all-reduce be paired with a 40-byte one.  train.main now gives each thread its own group; here the
+    count stream stays live while summ runs four times, one rank delayed on both paths: every count and every validation mean
+    must still be the single-process value."""
+    out = str(tmp_path / 't.pt')
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_two_thread_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert got['got'] == got['want']
+    from argsim_amd.train import summ
+    rng = np.random.default_rng(9)
+    glob = []
+    for _ in range(40):
+        ids = np.ones((8, 10), np.int32)
+        for b in range(8):
+            n = int(rng.integers(1, 11)); ids[b, :n] = rng.integers(3, 50, n)
+        glob.append(ids)
+    one = summ(_EvalStub(), np.concatenate(glob[:5]), 5)
+    for s in got['sums']:
+        assert np.allclose(s, one, rtol=1e-6, atol=0)

@@ -379,7 +379,7 @@ def test_compact_layout_changes_nothing(B, S, dtype):
     only (row_map: the place of (t, b) among the positions a row's steps cover, time-major; GruArgs::rowmap), the GEMMs over them
     take the device-side row count, the pick / the token compaction read through the map.  Against the padded layout with every
     step of every row run (compact = 0, skip_pad = 0), source != target, a one-token row, and target rows with an eos id in the
-    MIDDLE (the decoder mask is per position, model.py:161: such a row's steps end behind its LAST real id): z and the per-token
+    MIDDLE (the decoder mask is per position, model.py:161: such a row's steps end behind its LAST real id), an all-eos source row: z and the per-token
     losses bit for bit in fp32 (a GEMM row's products do not depend on which row of the operand it is), gradients to float-atomic
     order."""
     from argsim_amd import synth
@@ -395,6 +395,7 @@ def test_compact_layout_changes_nothing(B, S, dtype):
         if n >= 3:
             tgt[b, n // 2] = 1
     src[11, 2] = 1                                   # and of a source row (its length is the COUNT of non-eos ids, model.py:84)
+    src[23, :] = 1                                   # a source row without a single id: undefined in the reference (gather_nd at -1); zeros picked, no gradient, in both layouts
     out = {}
     for c in (1, 0):
         m.set_option('compact', c)
