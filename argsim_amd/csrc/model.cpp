@@ -452,7 +452,11 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
     // the table-fed layers: 112 tiles for 768 slots, 49 TFLOP/s).  64x64 tiles: four times the tiles, deterministic.
     if (h->dyn_thin && dyn_kind == 1 && h->cfg.compute_dtype == 0 && nt <= 4 && tiles <= 512 && K >= 1024)
         return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 2);
-    // (the same for the forward projection of the present target ids, 768 static tiles: measured, no change)
+    // The forward projection of the present target ids (static bound V rows x 3D: 768 tiles of 128x128, about 40 % of them real): 32x128
+    // tiles fill the chip with the rows that exist (78 -> 54 us; the encoder's, 1536 static tiles, is faster on 128x128).  Any tile
+    // form keeps a row's K order: the bits of gi do not move.
+    if (h->dyn_thin && dyn_kind == 1 && h->cfg.compute_dtype == 0 && tiles <= 768 && nt > 4 && K <= 512 && !accumulate)
+        return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 1);
     if (tiles > 256 && tiles % 256 != 0) {
         int main_mt = mt;
         while (main_mt > 0 && (main_mt * nt) % 256 != 0) --main_mt;
@@ -1056,7 +1060,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
                 AV_TRY(gemm_tn16(h, w.dgh16_e + d * 3 * D, nullptr, 6 * D, w.acth_e[i] ? w.e_hp16[d][i] : nullptr, w.e_hp[d][i], D, G + p.R + (int64_t)d * 3 * D * D, D, 3 * D, D, rs, 1.f, cdyn));
             if (i > 0) AV_TRY(gemm_bf16_pre(h, w.dgi16_e, 6 * D, false, P + p.W, In, true, dx, In, rs, In, Gc, 1.f, 0, 1, cdyn, cdyn ? 1 : 0));
             if (top1) {
-                AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
+                AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
                 AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In, cmap));
             }
             cur ^= 1;
@@ -1102,7 +1106,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         if (i > 0)
         AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, top1 ? 3 * D : 6 * D, 1.f, nullptr, 0, 0, cdyn, cdyn ? 1 : 0, true));
         if (top1) {       // the backward direction's input gradient lands on the rows at len_b - 1
-            AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D));
+            AV_TRY(gemm(h, false, true, w.dgib, 3 * D, P + oWb, In, w.dxl, In, B, In, 3 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));      // (B rows: the skinny form, 43 -> 16 us)
             AV_CHECK(pick_last_add(st, dx, w.dxl, w.lens_src, B, In, cmap));
         }
         cur ^= 1;

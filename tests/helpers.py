@@ -39,6 +39,9 @@ BIG_CASES = {
     # round 4: a batch WITHOUT a team-kernel geometry of its own -- 100 rows run in the 128-slot geometry with 28 phantom
     # rows, the compact layout whatever the fill, table-fed first layers below the vocabulary size (1 200 tokens >= 1 024)
     'phantom100': (dict(dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3), 100, 12, 'ragged', {}),
+    # BASELINE configs[0] as worded: src/config.json dims, batch 32, rows 0..31 of the 1 000 IAC posts encoded with the 8k SentencePiece
+    # model trained in the build container and capped to 64 pieces (tests/golden/make_configs0_golden.py)
+    'cfg0real': (dict(dim_tgt=8192, dim_emb=512, dim_rep=1024, rnn_layers=3), 32, 64, 'configs0', {}),
 }
 
 
@@ -58,7 +61,13 @@ def make_case(name, seed=0, pad=2, bias_scale=0.1):
         lens = rng.integers(2, S + 1, B)
         lens[[0, B // 2]] = S
         lens[1] = 1
-    if isinstance(lens, str) and lens == 'synth':      # the bench batch (FULL Zipf rows), eos-padded like every other case
+    if isinstance(lens, str) and lens == 'configs0':   # real text: the committed ids of tests/golden/configs0_ids.npz
+        import os
+        with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'configs0_ids.npz'), allow_pickle=False) as f:
+            real = f['ids'][:B].astype(np.int32)
+        ids[:, :S] = real
+        lens = [int((r != cfg['eos']).sum()) for r in real]
+    elif isinstance(lens, str) and lens == 'synth':      # the bench batch (FULL Zipf rows), eos-padded like every other case
         from argsim_amd import synth
         ids[:, :S] = synth.batch(B, S, V, seed=0)
         lens = [S] * B

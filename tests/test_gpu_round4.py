@@ -149,3 +149,101 @@ def test_same_seed_gives_bit_identical_losses_at_the_bench_geometry(opts):
     z = [m.encode(ids).tobytes() for _ in range(2)]
     assert z[0] == z[1]
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ phantom rows, per variable
+def test_phantom_row_geometry_against_the_oracle_fixture():
+    """A batch WITHOUT a team-kernel geometry of its own (100 rows, the reference's batch_train, src/config.json:26): the GRU
+    launches run with 128 slots of which 28 hold phantom rows, in the compact layout whatever the fill, with table-fed first layers
+    below the vocabulary size (1 200 tokens >= 1 024) -- the id-grouped summation of dE and of layer 1's dW.  Round 3 held this path
+    against the register-form path by ONE global gradient-norm ratio; here every variable is checked against the float64 oracle's
+    fixture (norm and a fixed projection), so a dead or wrong small block -- a bias, one direction's R -- cannot hide."""
+    gold = _gold('phantom100')
+    cfg, P, ids, keep, eps = make_case('phantom100')
+    assert np.array_equal(ids, gold['ids'])
+    m = _vae(cfg, P)
+    m.step = 20000
+    z = m.encode(ids)
+    assert np.abs(z - gold['mu']).max() <= 2e-5
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    assert m.present_ids()[0] > 0 and m.present_ids()[1] > 0                  # table-fed below the vocabulary size
+    lg, lk, lo = m.losses()
+    for got, key in ((lo, 'loss'), (lg, 'loss_gen'), (lk, 'loss_kld')):
+        assert abs(got - float(gold[key])) <= 2e-5 * abs(float(gold[key])) + 1e-7, key
+    assert np.abs(m.train_ce() - gold['loss_gen_samp']).max() <= 1e-4
+    bad = {}
+    for k, g in m.get_grads().items():
+        g = g.astype(np.float64)
+        n = float(gold['gnorm/' + k])
+        p = _probe(k, g.shape)
+        e = max(abs(np.linalg.norm(g) - n) / n if n > 0 else float(np.abs(g).max()),
+                abs(float((g * p).sum()) - float(gold['gdot/' + k])) / (n * np.linalg.norm(p)) if n > 0 else 0.0)
+        if e > 2e-4:
+            bad[k] = e
+    assert not bad, bad
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs[0] as worded
+def test_configs0_real_text_parity_step_against_the_oracle_fixture():
+    """BASELINE configs[0]: "src/config.json defaults, 1k-sentence IAC subset, SentencePiece vocab 8k, seq_len 64, batch 32".  One
+    training step at the config.json dimensions (dim_rep 1024, src/config.json:10-21) over rows 0..31 of the 1 000 IAC posts of
+    tests/golden/configs0_ids.npz -- real text from the reference's docs/results_iac/clustering.csv, tokenised in the build
+    container with the 8k SentencePiece model trained there on the reference's trainer flags (util_sp.py:24-39) and capped to 64
+    pieces (util_sp.py:42-63; make_configs0_golden.py) -- against the float64 oracle's fixture: losses, mu, log sigma^2, per-token
+    CE, every gradient (norm and one projection per variable)."""
+    gold = _gold('cfg0real')
+    cfg, P, ids, keep, eps = make_case('cfg0real')
+    assert np.array_equal(ids, gold['ids']) and cfg['dim_rep'] == 1024 and ids.shape[0] == 32
+    m = _vae(cfg, P)
+    m.step = 20000
+    z, lv = m.encode(ids, return_lv=True)
+    assert np.abs(z - gold['mu']).max() <= 2e-5 and np.abs(lv - gold['lv']).max() <= 2e-5
+    m.forward_backward(ids, ids, keep_mask=keep, eps=eps)
+    lg, lk, lo = m.losses()
+    for got, key in ((lo, 'loss'), (lg, 'loss_gen'), (lk, 'loss_kld')):
+        assert abs(got - float(gold[key])) <= 2e-5 * abs(float(gold[key])) + 1e-7, key
+    assert np.abs(m.train_ce() - gold['loss_gen_samp']).max() <= 1e-4
+    for k, g in m.get_grads().items():
+        g = g.astype(np.float64)
+        n = float(gold['gnorm/' + k])
+        assert abs(np.linalg.norm(g) - n) <= 2e-4 * n, k
+        p = _probe(k, g.shape)
+        assert abs(float((g * p).sum()) - float(gold['gdot/' + k])) <= 2e-4 * n * np.linalg.norm(p), k
+    m.close()
+
+
+def test_configs0_training_driver_over_the_real_text(tmp_path):
+    """The same configuration through argsim_amd.train.main (src/train.py:54-121): train.txt is the DECODE of the capped ids, as
+    src/data_iac.py:40-41 writes it, the vocabulary is the committed 8k model, the model section is src/config.json's (dim_rep
+    1024), batch 32, max_len 64; the batch generator tokenises the text again (encode_capped over the 8k vocabulary, vpack, the
+    prefetch pipe), the loop trains 60 steps, validates twice over 96 held-out posts and writes a checkpoint.  The re-tokenised
+    rows must be the committed ids (SentencePiece decode / encode round trip), the validation CE must fall."""
+    import json
+    from argsim_amd import train, util_sp
+    here = os.path.join(HERE, 'golden')
+    vocab = util_sp.load_spm(os.path.join(here, 'configs0_vocab.model'))
+    assert vocab.get_piece_size() == 8192
+    with np.load(os.path.join(here, 'configs0_ids.npz'), allow_pickle=False) as f:
+        ids = f['ids'].astype(np.int32)
+    assert ids.shape == (1000, 64)
+    rows = [[int(t) for t in r if t != 1] for r in ids]
+    lines = [vocab.decode_ids(r) for r in rows]
+    same = sum(util_sp.encode_capped(vocab, t, cap=64) == r for t, r in zip(lines, rows))
+    assert same >= 990, same                      # (a handful of rows may re-segment across a removed piece boundary)
+    d = tmp_path
+    (d / 'data').mkdir()
+    open(d / 'data' / 'train.txt', 'w').write('\n'.join(lines[:904]) + '\n')
+    np.save(d / 'data' / 'valid.npy', ids[904:])
+    cfgj = {"paths": {"log": str(d / 'log'), "vocab": os.path.join(here, 'configs0_vocab.model'), "train": str(d / 'data' / 'train.txt'),
+                      "valid": str(d / 'data' / 'valid.npy'), "ckpt": str(d / 'ckpt')},
+            "model": {"accelerate": 1e-4, "learn_rate": 1e-3, "dim_tgt": 8192, "dim_emb": 512, "dim_rep": 1024, "rnn_layers": 3,
+                      "bidirectional": True, "bidir_stacked": True, "attentive": False, "logit_use_embed": True},      # src/config.json:10-21
+            "train": {"seed": 0, "max_len": 64, "batch_train": 32, "batch_valid": 32, "total_valid": 96}}
+    json.dump(cfgj, open(d / 'config.json', 'w'))
+    train.main(['--config', str(d / 'config.json'), '--trial', 'c0', '--rounds', '1', '--steps-per-round', '60', '--valid-every', '30', '--prefetch', '4'])
+    recs = [json.loads(l) for l in open(d / 'log' / 'c0.jsonl')]
+    assert [r['step'] for r in recs] == [30, 60]
+    assert all(np.isfinite([r['step_errt'], r['step_loss_gen'], r['step_loss_kld'], r['sentences_per_sec']]).all() for r in recs)
+    assert recs[1]['step_loss_gen'] < recs[0]['step_loss_gen'] < np.log(8192.0) + 0.5
+    assert (d / 'ckpt' / 'c00.npz').exists()
