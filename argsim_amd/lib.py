@@ -11,6 +11,22 @@ LIB_PATH = os.path.join(_HERE, 'libargsim_vae.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 
+def source_digest():
+    """sha1 over the kernel and host sources the library is built from (csrc/*.hip, *.cpp, *.h and the C-ABI header): names a
+    build.  The committed rocprofv3 summaries under profiles/ record it (scripts/summarize_profile.py) and bench.py only quotes
+    their counters for the SAME sources -- the GPU box has no .git to ask for a commit."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')) + glob.glob(os.path.join(CSRC, '*.h')))
+    files.append(os.path.join(os.path.dirname(_HERE), 'include', 'argsim_vae.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class AvaeConfig(C.Structure):
     _fields_ = [('dim_tgt', C.c_int32), ('dim_emb', C.c_int32), ('dim_rep', C.c_int32), ('rnn_layers', C.c_int32),
                 ('accelerate', C.c_float), ('learn_rate', C.c_float), ('bos', C.c_int32), ('eos', C.c_int32),

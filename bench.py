@@ -31,7 +31,22 @@ B, S = 256, 64
 PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA = 2500.0    # TFLOP/s dense (same table)
 STAMP_EVERY = 8            # every n-th timed step carries the per-launch HIP-event stamps of the roofline leg
-PMC_TAG = 'r03'            # the committed rocprofv3 --pmc passes `traffic` / `mfma_busy` are read from
+PMC_TAG = 'r04'            # the committed rocprofv3 --pmc passes `traffic` / `mfma_busy` are read from (quoted only for the same sources: pmc_summary)
+
+
+def pmc_summary(name):
+    """the committed counter summary profiles/<name>_pmc_summary.json, or (None, why): its counters describe the kernels of the
+    sources it was taken on (source_digest recorded by scripts/summarize_profile.py), so a summary of other sources is NOT quoted"""
+    from argsim_amd.lib import source_digest
+    path = os.path.join(ROOT, 'profiles', name + '_pmc_summary.json')
+    try:
+        pm = json.load(open(path))
+    except Exception:
+        return None, "no committed counter passes (%s)" % os.path.relpath(path, ROOT)
+    if pm.get('source_digest') != source_digest():
+        return None, "the committed counter passes %s were taken on other kernel sources (digest %s, this build %s): not quoted" % (
+            os.path.relpath(path, ROOT), pm.get('source_digest'), source_digest())
+    return pm, None
 
 
 def host_cores():
@@ -109,13 +124,10 @@ def side_config(label, dtype, b, s, steps=3, warmup=2, pmc=None, ragged=None, **
            "gemm_frac_of_peak": (tm['gemm'][2] / (tm['gemm'][0] * 1e-3) / 1e12 / peak) if tm['gemm'][0] > 0 else None,
            "gemm_peak_tflops": peak}
     if pmc:        # the committed rocprofv3 --pmc passes of THIS configuration (scripts/profile_round.sh), per GEMM-class launch
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles/%s_%s_pmc_summary.json' % (PMC_TAG, pmc))))
-            out["traffic"] = pm['gemm_class']['hbm_bytes_per_dispatch']
-            out["mfma_busy"] = pm['gemm_class'].get('mfma_busy')
-            out["traffic_unit"] = "HBM bytes per GEMM-class launch, from the committed PMC passes profiles/%s_%s_pmc_summary.json (not measured by this run)" % (PMC_TAG, pmc)
-        except Exception:
-            out["traffic"] = out["mfma_busy"] = None
+        pm, why = pmc_summary('%s_%s' % (PMC_TAG, pmc))
+        out["traffic"] = pm['gemm_class']['hbm_bytes_per_dispatch'] if pm else None
+        out["mfma_busy"] = pm['gemm_class'].get('mfma_busy') if pm else None
+        out["traffic_unit"] = ("HBM bytes per GEMM-class launch, from the committed PMC passes profiles/%s_%s_pmc_summary.json of these sources (not measured by this run)" % (PMC_TAG, pmc)) if pm else why
     m.close()
     del m, ids
     torch.cuda.empty_cache()
@@ -243,6 +255,13 @@ def main():
                        "gru": "stepwise" if A.stepwise else "persistent"},
             "loss": losses[2],
         }
+        if dp:
+            # what the collective layer really did, so that a scaling record can be checked: the world size the process group
+            # reports (RCCL's, backend nccl), the buckets announced per step and the bytes summed per rank and step
+            out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "buckets_per_step": len(model.buckets()),
+                           "bytes_reduced_per_rank_per_step": 4 * sum(c for _, c in model.buckets()),
+                           "overlap": "bucketed all-reduce from the backward hook on a side HIP stream, fenced before every persistent GRU launch",
+                           "note": "no multi-GPU scaling curve has been measured for this build yet (RCCL with world > 1 only runs in the driver's scaling bench)" if world > 1 else "single-GPU rehearsal of the data-parallel path"}
         if timing:
             tm = model.timing_collect()
             model.set_option('timing', 0)
@@ -252,19 +271,17 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = mfma_busy = None
             pmc_file = 'profiles/%s%s_pmc_summary.json' % (PMC_TAG, '' if A.dtype == 'f32' else '_' + A.dtype)
-            try:   # per launch of this kernel class, from the COMMITTED rocprofv3 --pmc passes of this same command
-                   # (scripts/profile_round.sh + summarize_profile.py; FETCH_SIZE doubled per the gfx950 rule): not a
-                   # measurement of this run
-                pm = json.load(open(os.path.join(ROOT, pmc_file)))
-                if name == 'gemm':
-                    traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
-                    mfma_busy = pm['gemm_class'].get('mfma_busy')
-            except Exception:
-                pass
+            # per launch of this kernel class, from the COMMITTED rocprofv3 --pmc passes of this same command (scripts/profile_round.sh
+            # + summarize_profile.py; FETCH_SIZE doubled per the gfx950 rule): not a measurement of this run, and quoted only while
+            # the kernel sources are the ones the passes were taken on
+            pm, why = pmc_summary('%s%s' % (PMC_TAG, '' if A.dtype == 'f32' else '_' + A.dtype))
+            if pm and name == 'gemm':
+                traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
+                mfma_busy = pm['gemm_class'].get('mfma_busy')
             peak = PEAK_F32_MFMA if (A.dtype == 'f32' or name != 'gemm') else (PEAK_BF16_MFMA if A.dtype == 'bf16' else PEAK_BF16_MFMA / 6.0)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch, from the committed PMC passes %s (not measured by this run)" % pmc_file,
+                               "traffic_unit": ("HBM bytes per launch, from the committed PMC passes %s of these sources (not measured by this run)" % pmc_file) if pm else why,
                                "mfma_busy": mfma_busy,
                                "flops_per_launch": fl / max(n, 1),
                                "launches_per_step": n / nst, "avg_launch_ms": ms / max(n, 1), "stamped_steps": nst,
@@ -326,6 +343,44 @@ def main():
                                  "padded_step_share": 1.0 - float((ids_r != 1).sum()) / float(B * int((ids_r != 1).sum(1).max())),
                                  "what": "same model, RAGGED synthetic batch %d x %d (LogNormal lengths); not the headline" % (B, S)}
                 out["graph_as_written"] = leg({'table_l1': 0, 'enc_top1': 0}, "both off: every FLOP of the reference's graph executed (2 153 GFLOP per step)")
+                # Data-parallel overlap rehearsed on ONE GPU: the bucket hook live, and for every announced bucket a
+                # stand-in for its all-reduce on a side stream -- device-local copies moving 2 x the bucket's bytes in and out, what a
+                # reduce-scatter + all-gather touches in HBM -- fenced before every persistent GRU launch exactly as GradReducer fences
+                # RCCL.  It prices what side-stream traffic beside backward costs the step on this GPU (the persistent GEMM's static
+                # schedule assumes an otherwise idle chip); it says nothing about xGMI time: no peer, no RCCL kernel.
+                side = torch.cuda.Stream(model.device)
+                scratch = torch.empty(max(c for _, c in model.buckets()), dtype=torch.float32, device=model.device)
+
+                def rehearsal_hook(bucket, off, cnt):
+                    cur = torch.cuda.current_stream(model.device)
+                    if bucket < 0:
+                        cur.wait_stream(side)
+                        return
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        scratch[:cnt].copy_(model.grads[off:off + cnt])
+                        model.grads[off:off + cnt].copy_(scratch[:cnt])
+
+                def rehearse(n):
+                    for i in range(n):
+                        model.forward_backward(ids, ids, seed=2 * 10 ** 6 + i)
+                        torch.cuda.current_stream(model.device).wait_stream(side)
+                        model.adam_step()
+                model.set_grad_hook(rehearsal_hook)
+                rehearse(2)
+                fence()
+                t1 = time.perf_counter()
+                rehearse(A.steps)
+                fence()
+                dth = (time.perf_counter() - t1) / A.steps
+                model.set_grad_hook(None)
+                out["dp_overlap_rehearsal"] = {
+                    "ms_per_step": 1e3 * dth, "ms_cost_vs_headline": 1e3 * dth - out["ms_per_step"], "buckets_per_step": len(model.buckets()),
+                    "bytes_per_step": 4 * sum(c for _, c in model.buckets()),
+                    "what": "one GPU, bucket hook live, a device-local stand-in for every bucket's all-reduce on a side stream (2 x bucket bytes read and "
+                            "written), fenced before each persistent GRU launch: the cost of side-stream traffic beside backward, NOT a multi-GPU measurement"}
             if not A.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         if world == 1 and A.dtype == 'f32' and not A.no_alt and headline:

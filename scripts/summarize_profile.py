@@ -13,7 +13,9 @@ suffix = sys.argv[2] if len(sys.argv) > 2 else ''          # e.g. _f32s
 os.makedirs('profiles', exist_ok=True)
 ks = glob.glob('gpurun_out/%s_trace/**/*kernel_stats.csv' % tag, recursive=True)[0]
 shutil.copy(ks, 'profiles/%s%s_kernel_stats.csv' % (tag, suffix))
-out = {'units': 'bytes per dispatch (mean); fetch doubled per the gfx950 correction; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / '
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from argsim_amd.lib import source_digest  # noqa: E402
+out = {'source_digest': source_digest(), 'units': 'bytes per dispatch (mean); fetch doubled per the gfx950 correction; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / '
                 '(GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / dispatch duration (profiled pass)',
        'kernels': {}}
 
