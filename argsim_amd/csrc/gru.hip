@@ -631,6 +631,14 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
             const unsigned aoff = a_offset(p, row0, len_a);
             const __amdgpu_buffer_rsrc_t rs = (p == 0 && !BF) ? rs_h0 : rs_hs;
             if constexpr (!PIPE) {
+                // GruArgs::spec (few rows alive per step: the step is the latency of one chain, the texture addresser is idle): the
+                // fragment is loaded at once, WITHOUT the probe's round trip in front of it; complete -> the step goes on one L2
+                // round trip earlier.  A wave whose fragment still carries a sentinel takes the polling path below.
+                bool got = false;
+                if (poll && a.spec) {
+                    frag_issue<NQA>(ra, rs, aoff, q_stride(p));
+                    if constexpr (BF) got = !frag_bad16<NQA>(ra); else got = !frag_bad<NQA>(ra);
+                }
                 if (poll) {
                     // ONE wave per team polls the exchange and releases its three K-split partners through an LDS
                     // word: four independent polls would leave the partners up to a poll period (~1 us) apart and
@@ -638,18 +646,20 @@ __global__ __launch_bounds__(1024, 4) void gru_fwd_team_kernel(GruArgs a)
                     // stores for these 16 rows: one 256-byte request per poll) is a start signal only; every wave
                     // still verifies its own fragment dword by dword below.
                     if (wk == 0) {
+                        if (!got) {
                         const int prow = row0 + 15;
                         const int plen = len_p0;                     // (!PIPE: one row block, fetched once before the loop)
                         const float* pp = BF ? xh + (xch16_index(pos_map(p - 1, plen, J.reverse) + 1, prow, (lane & 31) * 16 + 15, B, D) >> 1)      // (the high half of its dword)
                                              : xh + xch_index(pos_map(p - 1, plen, J.reverse), prow, (lane & 31) * 16 + 15, B, D);
                         SpinGuard sg;
                         while (__any(BF ? (load4_sc1(pp) >> 16) == 0xffffu : load4_sc1(pp) == kSentinel) && !sg.expired(a.err)) { }
+                        }
                         if (lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else {
+                    } else if (!got) {
                         while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                frag_issue<NQA>(ra, rs, aoff, q_stride(p));
+                if (!got) frag_issue<NQA>(ra, rs, aoff, q_stride(p));
             }
             if (poll) { if constexpr (BF) frag_ensure16<NQA>(ra, rs, aoff, a.err, q_stride(p)); else frag_ensure<NQA>(ra, rs, aoff, a.err, q_stride(p)); }
         } else if constexpr (!PIPE) {

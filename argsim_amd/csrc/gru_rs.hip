@@ -213,17 +213,20 @@ __global__ __launch_bounds__(1024, 4) void gru_bwd_rs_kernel(GruArgs a)
                 }
             };
             if constexpr (!PIPE) {
-                // ONE load site: the first pass polls with one wave per team (a poll costs ~180 texture-addresser cycles), which
+                // ONE load site: the first polling pass polls with one wave per team (a poll costs ~180 texture-addresser cycles), which
                 // releases its partners through LDS; a pass that still met an old tag is repeated by the wave itself
-                for (bool first = true;; first = false) {
-                    if (wk == 0 || !first) probe();
-                    if (first) {
+                // (GruArgs::spec -- few rows alive, the step is one chain's latency: pass 0 loads at once, without the probe's round
+                //  trip in front; a pass that met an old tag goes on to the polling passes)
+                for (int att = a.spec ? 0 : 1;; ++att) {
+                    if (att >= 1 && (wk == 0 || att > 1)) probe();
+                    if (att == 1) {
                         if (wk == 0) { if (lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
                         else while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1u) __builtin_amdgcn_s_sleep(1);
                     }
                     issue8(off);
                     if (all_tagged(tag) || sg.expired(p_err)) break;
                 }
+                if (wk == 0 && lane == 0) __hip_atomic_store(ready, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (a pass 0 that succeeded: partners that did not are waiting)
             } else {
                 while (!all_tagged(tag) && !sg.expired(p_err)) { probe(); issue8(off); }
             }

@@ -112,6 +112,7 @@ struct GruArgs {
     int force_slow;       // 1: never use the same-XCD L2 fast path
     int sv16;             // 1 (bf16 team kernels, forward AND backward of a layer): the saved gates r, u, n, hn are stored as bf16
     int bf16;             // 1 (compute_dtype 1): the team kernels round both operands of the recurrent product to bf16
+    int spec;             // 1 (team kernels, one row block per workgroup): few rows are alive per step -- a consumer loads its operand at once, without a probe round trip in front (speed only)
     int bwd_rs;           // 1: the backward runs the reduce-scatter team kernel (gru_rs.hip) where the team geometry applies and xbuf holds its ring
     int ablate;           // timing experiments only: 1 no MFMA/A loads, 2 no gate-phase loads, 4 no saves, 8 cheap activations, 16 no sync
 };

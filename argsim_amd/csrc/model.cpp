@@ -64,6 +64,7 @@ struct avae_ctx {
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
+    int gru_spec = 1;     // team kernels load a consumer's operand at once, without a probe round trip in front of it (measured: never slower; RAGGED 256 x 64 10.41 -> 10.23 ms): 0 never, 1 always, 2 where few rows are alive per step (spec_pick)
     int bwd_rs = 2;       // fp32 BPTT team kernels in the reduce-scatter form (gru_rs.hip: own gate columns x resident R slice, partial dH summed through the
                           // exchange): 0 never, 1 wherever the geometry allows, 2 auto -- where few rows are alive per step (rs_pick)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)
@@ -556,10 +557,18 @@ static double expected_fill(const avae_ctx* h)
 // Which BPTT team kernel a launch of njobs jobs over B rows takes (option bwd_rs = 2): the reduce-scatter form stores 64 KB per live
 // row and step where the other form stores 6 KB, so it pays where few rows are alive -- measured break-even at about 220 live
 // row-chains per step (RAGGED 256 x 64 at fill 0.44: a tie; batch 100 x 512 ragged: -8 % of the step; FULL 256 x 64: +5 %).
+static bool few_rows(const avae_ctx* h, int njobs, int B) { return expected_fill(h) * B * njobs < 200.0; }
 static int rs_pick(const avae_ctx* h, int njobs, int B)
 {
     if (h->bwd_rs != 2) return h->bwd_rs;
-    return expected_fill(h) * B * njobs < 200.0 ? 1 : 0;
+    return few_rows(h, njobs, B) ? 1 : 0;
+}
+// the same regime in the exchange of every team kernel (option gru_spec = 2): a consumer's first operand load goes out without a probe
+// round trip in front of it (GruArgs::spec).  With many teams alive the probe is what keeps the texture addresser free.
+static int spec_pick(const avae_ctx* h, int njobs, int B)
+{
+    if (h->gru_spec != 2) return h->gru_spec;
+    return few_rows(h, njobs, B) ? 1 : 0;
 }
 
 // -------------------------------------------------------------------------------- forward pieces
@@ -731,6 +740,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         }
         attach_order(h, w, a, true, top1 ? 1 : 0);
         a.rowmap = cmap;
+        a.spec = spec_pick(h, a.njobs, B);
         { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         if (top1) {
@@ -811,6 +821,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         }
         if (T > 1) attach_order(h, w, a, true, 2);
         a.rowmap = cmap;
+        a.spec = spec_pick(h, 1, B);
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.d_hd[i];
@@ -942,7 +953,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         attach_order(h, w, a, false, 2);
         a.rowmap = dmap;
         if (dmap && i == 0) j.dgi_by_pos = 1;       // (table-fed: its gate gradients are summed by token id)
-        a.bwd_rs = rs_pick(h, 1, B);
+        a.bwd_rs = rs_pick(h, 1, B); a.spec = spec_pick(h, 1, B);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -1037,7 +1048,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         attach_order(h, w, a, false, top1 ? 1 : 0);
         a.rowmap = cmap;
         if (cmap && i == 0) for (int d = 0; d < a.njobs; ++d) a.job[d].dgi_by_pos = 1;      // (table-fed: its gate gradients are summed by token id)
-        a.bwd_rs = rs_pick(h, a.njobs, B);
+        a.bwd_rs = rs_pick(h, a.njobs, B); a.spec = spec_pick(h, a.njobs, B);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
@@ -1333,6 +1344,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
     if (!strcmp(key, "bwd_rs")) { h->bwd_rs = value; return 0; }
+    if (!strcmp(key, "gru_spec")) { h->gru_spec = value; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
     if (!strcmp(key, "bf16_sv")) { h->bf16_sv = value != 0; return 0; }
