@@ -7,7 +7,7 @@ from argsim_amd.model import VAE
 key = sys.argv[1]
 B, S = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 64)
 VALS = [int(x) for x in os.environ.get('VALS', '0,1').split(',')]
-m = VAE('train', seed=0, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+m = VAE('train', seed=0, dtype=os.environ.get('DTYPE', 'f32'), dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
 m.step = 20000
 ids = torch.as_tensor(synth.batch(B, S, 8192, ragged=bool(os.environ.get('RAGGED')), seed=0)).cuda()
 for i in range(3): m.train_step(ids, ids, seed=i)
