@@ -64,7 +64,8 @@ struct avae_ctx {
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
-    int gru_spec = 1;     // team kernels load a consumer's operand at once, without a probe round trip in front of it (measured: never slower; RAGGED 256 x 64 10.41 -> 10.23 ms): 0 never, 1 always, 2 where few rows are alive per step (spec_pick)
+    int gru_spec = 2;     // team kernels load a consumer's operand at once, without a probe round trip in front of it: 0 never, 1 always, 2 where few rows are alive per
+                          // step (spec_pick: RAGGED 256 x 64 10.41 -> 10.23 ms; always-on costs a FULL 100 x 512 batch 1 %, 71.5 -> 72.3 ms, and a FULL 256 x 64 nothing)
     int bwd_rs = 2;       // fp32 BPTT team kernels in the reduce-scatter form (gru_rs.hip: own gate columns x resident R slice, partial dH summed through the
                           // exchange): 0 never, 1 wherever the geometry allows, 2 auto -- where few rows are alive per step (rs_pick)
     int gru_bf16 = 1;     // compute_dtype 1 only: the recurrent product of the team kernels takes bf16 operands too (0: fp32 recurrence)

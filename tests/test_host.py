@@ -251,3 +251,29 @@ def test_checkpoint_audit_is_loud():
     m = Stub()
     ckpt.load_state_dict(m, {'a/kernel': good['a/kernel']}, strict=False)      # partial 'infer' restore
     assert list(m.got) == [('a/kernel', 0)]
+
+
+def test_bench_quotes_committed_counters_only_for_the_sources_they_were_taken_on(tmp_path, monkeypatch):
+    """`roofline.traffic` / `mfma_busy` on the bench line come from a COMMITTED rocprofv3 summary, which goes stale
+    the moment a kernel changes.  The summary records the digest of the kernel sources it was taken on (argsim_amd.lib.source_digest,
+    written by scripts/summarize_profile.py); bench.pmc_summary hands it out only for the same digest and otherwise says why."""
+    import importlib
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    from argsim_amd.lib import source_digest
+    d = source_digest()
+    assert len(d) == 16 and d == source_digest()
+    (tmp_path / 'profiles').mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    pm, why = bench.pmc_summary('rXX')
+    assert pm is None and 'no committed counter passes' in why
+    json.dump({'source_digest': d, 'gemm_class': {'hbm_bytes_per_dispatch': 1.0}}, open(tmp_path / 'profiles' / 'rXX_pmc_summary.json', 'w'))
+    pm, why = bench.pmc_summary('rXX')
+    assert pm is not None and why is None and pm['gemm_class']['hbm_bytes_per_dispatch'] == 1.0
+    json.dump({'source_digest': '0' * 16, 'gemm_class': {}}, open(tmp_path / 'profiles' / 'rXX_pmc_summary.json', 'w'))
+    pm, why = bench.pmc_summary('rXX')
+    assert pm is None and 'other kernel sources' in why
