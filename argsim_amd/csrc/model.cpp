@@ -8,6 +8,10 @@
 #include "../../include/argsim_vae.h"
 #include "kernels.h"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -51,11 +55,13 @@ struct avae_ctx {
     int gru_ablate = 0, gru_force_slow = 0, gru_stagger = 0, gru_item = 2;
     int skinny = 1;       // a few rows (latent block, one-step top layer; backward: remainder rows, small products): one 32x32 tile per workgroup,
                           // K split over its waves (gemm_f32.hip); 0: the tiled forms
-    const int* expect_ptr[2] = {nullptr, nullptr}; int expect_val[2] = {0, 0};      // (dyn_expected)
+    const int* expect_ptr[3] = {nullptr, nullptr, nullptr}; int expect_val[3] = {0, 0, 0};      // (dyn_expected)
     int rows_form = 0;    // one-shot: the next gemm() call's rows are the batch rows -- skinny form whatever the batch size (see gemm)
     int compact = 2;      // encoder activations stored over the REAL rows only (row_map / GruArgs::rowmap): padded rows of a ragged batch cost nothing in the
                           // encoder's GEMMs.  0 off, 1 on, 2 auto: on where the share of real positions the previous calls reported is below 0.85 (fill_hint)
     int skip_pad = 1;     // team GRU kernels skip the steps behind a row block's longest row (rows sorted by length, ops.hip row_order); 0: every step of every row
+    int shared_device = 0; int lock_fd = -1;      // option shared_device: persistent launches are taken one at a time ACROSS processes (DeviceTurn)
+    int dyn_split = 1;    // ragged batches: narrow backward GEMMs over few expected rows split K instead of leaving the chip at one workgroup per CU (gemm())
     int dyn_thin = 1;     // device-row-count GEMMs with a narrow output run 64x64 tiles (gemm())
     int enc_top1 = 1;     // the top encoder layer's backward direction runs its ONE live step only (gru.hip "one step from a zero state"); 0: all S steps like the reference's graph
     int table_l1 = 1;     // layers fed by embedding rows project the TABLE once and gather / scatter by id where a batch has more tokens than the vocabulary (use_table)
@@ -117,6 +123,24 @@ int fail(avae_ctx* h, const std::string& m) { h->err = m; return 1; }
                             "run with avae_set_option(\"persistent\", 0)");                                         \
          if (e_ != hipSuccess) { char b_[512]; snprintf(b_, sizeof b_, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
              h->err = b_; return 1; } } while (0)
+
+// A persistent GRU launch needs every CU, so two PROCESSES computing on one device (several data-parallel ranks rehearsed on one
+// GPU, a second job) can each get part of the chip and both run into the 2 s exchange time-out.  Option shared_device = 1: every
+// persistent launch is taken in turn across processes -- an exclusive flock on a per-device lock file from before the launch
+// is enqueued until it has COMPLETED (one stream synchronisation per launch: slower, never wrong).  Non-persistent kernels of another
+// process only delay a persistent launch; they cannot strand it.
+struct DeviceTurn {
+    avae_ctx* h; bool held = false;
+    explicit DeviceTurn(avae_ctx* h_) : h(h_) {
+        if (!h->shared_device || !h->persistent) return;
+        if (h->lock_fd < 0) {
+            char path[64]; snprintf(path, sizeof path, "/tmp/argsim_vae_dev%d.lock", h->device);
+            h->lock_fd = open(path, O_CREAT | O_RDWR, 0666);
+        }
+        if (h->lock_fd >= 0 && flock(h->lock_fd, LOCK_EX) == 0) held = true;
+    }
+    ~DeviceTurn() { if (held) { (void)hipStreamSynchronize(h->stream); (void)flock(h->lock_fd, LOCK_UN); } }
+};
 
 // kernel classes for the timing hook: 0 = MFMA GEMM, 1 = GRU forward, 2 = GRU backward
 struct Timed {
@@ -323,7 +347,7 @@ int grow_bf16(avae_ctx* h, unsigned short** buf, size_t* cap, size_t need)
 static int dyn_expected(const avae_ctx* h, const int* dyn, int dyn_kind)
 {
     if (dyn_kind != 1 || !dyn) return 0;
-    for (int i = 0; i < 2; ++i) if (dyn == h->expect_ptr[i]) return h->expect_val[i];
+    for (int i = 0; i < 3; ++i) if (dyn == h->expect_ptr[i]) return h->expect_val[i];
     return 0;
 }
 // second problem of a pair (same shape, layout, scalars): see GemmArgs in kernels.h
@@ -436,6 +460,21 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
     const bool rows_form = h->rows_form != 0; h->rows_form = 0;
     if (rows_form && h->skinny && h->cfg.compute_dtype != 1 && !a_mc && split_k == 0 && dyn_kind == 0)
         return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, nullptr, 0, 3);
+    // Ragged batches (compact layout: the host knows roughly how many rows are real): a backward GEMM with a narrow output whose real rows
+    // make fewer 128x128 tiles than the chip has CUs (dho = dlogits E over 7.4 k of 16.6 k token rows: 232 tiles, ONE workgroup per CU,
+    // 105 TFLOP/s) splits K over ~768 workgroups instead (float atomics into the zero-filled output: the gradients carry that order anyway).
+    // The expectation only shapes the launch; rows beyond the device-side count are never touched either way.
+    if (allow_atomic && h->dyn_split && dyn_kind == 1 && !accumulate && ldc == N && h->cfg.compute_dtype == 0 && K >= 1536) {
+        const int expect = dyn_expected(h, dyn, dyn_kind);
+        if (expect > 0) {
+            const int eff_tiles = ((expect + 127) / 128) * nt;
+            const int sk = std::min(768 / std::max(eff_tiles, 1), K / 512);
+            if (eff_tiles <= 320 && sk >= 2) {
+                AV_CHECK(zero_rows_dyn(h->stream, C, dyn, M, N));
+                return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, 0, sk, dyn, dyn_kind);
+            }
+        }
+    }
     const bool prefer_skinny = allow_atomic && h->skinny && M <= 512 && K <= 2048 && h->cfg.compute_dtype != 1;
     const int thin_form = (allow_atomic && h->skinny) ? 3 : 1;
     if (tiles <= 96) {
@@ -452,8 +491,16 @@ int gemm(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float
     // A GEMM whose row count is only known on the device (the ids present in the batch: about V / 2 of the static bound
     // of V rows) with a narrow output: 128x128 tiles over the rows that exist are fewer than one round of the chip (dE of
     // the table-fed layers: 112 tiles for 768 slots, 49 TFLOP/s).  64x64 tiles: four times the tiles, deterministic.
-    if (h->dyn_thin && dyn_kind == 1 && h->cfg.compute_dtype == 0 && nt <= 4 && tiles <= 512 && K >= 1024)
+    if (h->dyn_thin && dyn_kind == 1 && h->cfg.compute_dtype == 0 && nt <= 4 && tiles <= 512 && K >= 1024) {
+        // (backward -- dE of the present ids, K = 3D or 6D: the K range split over 2-4 slices as well, float atomics into the zeroed rows:
+        //  3 584 x 512 x 3 072: 113 -> 96 us; fewer present ids, a ragged batch: more)
+        const int sk = std::min(4, K / 768);
+        if (allow_atomic && h->dyn_split && !accumulate && ldc == N && sk >= 2) {
+            AV_CHECK(zero_rows_dyn(h->stream, C, dyn, M, N));
+            return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, 0, sk, dyn, dyn_kind, 2);
+        }
         return gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, 1, dyn, dyn_kind, 2);
+    }
     // The forward projection of the present target ids (static bound V rows x 3D: 768 tiles of 128x128, about 40 % of them real): 32x128
     // tiles fill the chip with the rows that exist (78 -> 54 us; the encoder's, 1536 static tiles, is faster on 128x128).  Any tile
     // form keeps a row's K order: the bits of gi do not move.
@@ -644,7 +691,7 @@ static void attach_order(avae_ctx* h, const Ws& w, GruArgs& a, bool fwd, int k)
 int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
 {
     w.compact = false; w.compact_d = false;
-    h->expect_ptr[0] = h->expect_ptr[1] = nullptr;
+    h->expect_ptr[0] = h->expect_ptr[1] = h->expect_ptr[2] = nullptr;
     if (!h->compact || !h->persistent || Ss < 2 || !use_table(h, Ss * B, B)) return 0;
     const bool phantom = w.Bx != B;        // a batch without a team geometry of its own: the compact layout is what lets it run the team kernels at all
     if (phantom && !(w.ord_ok[0] && (w.ord_ok[1] || !top_one_step(h)))) return 0;
@@ -672,6 +719,7 @@ int build_compact(avae_ctx* h, Ws& w, int B, int Ss, int T, bool train)
         const double fill = (real > 0 && rows > 0) ? std::min(1.0, (double)real / (double)rows) : 0.0;
         h->expect_ptr[0] = w.nsrc; h->expect_val[0] = (int)(fill * Ss * B);
         h->expect_ptr[1] = w.ntgt; h->expect_val[1] = (int)(fill * T * B);
+        h->expect_ptr[2] = w.ntok; h->expect_val[2] = (int)(fill * T * B);      // (the unmasked decoder tokens: the same share of T x B for prefix masks)
     }
     // the decoder stack the same way (training / evaluation calls: T > 1): a row's steps end one behind its last non-eos target id
     if (T < 2 || !use_table(h, T * B, B) || h->compact == 3) return 0;      // (3: the encoder alone, for measurements)
@@ -743,6 +791,7 @@ int run_encoder(avae_ctx* h, Ws& w, int B, int Ss, bool save)
         a.rowmap = cmap;
         a.spec = spec_pick(h, a.njobs, B);
         { Timed t(h, 1, 2.0 * a.njobs * Ss * (double)B * D * 3 * D);
+          DeviceTurn turn(h);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         if (top1) {
             // the backward direction at position len_b - 1: gi = W_b x[len_b - 1] + bW_b for B rows, then one cell step from h = 0
@@ -824,6 +873,7 @@ int run_decoder_rnn(avae_ctx* h, Ws& w, int B, int T, const float* state_in, int
         a.rowmap = cmap;
         a.spec = spec_pick(h, 1, B);
         { Timed t(h, 1, 2.0 * T * (double)B * D * 3 * D);
+          DeviceTurn turn(h);
           AV_GRU(gru_forward(h->stream, a, h->persistent != 0)); }
         x = w.d_hd[i];
     }
@@ -957,6 +1007,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         a.bwd_rs = rs_pick(h, 1, B); a.spec = spec_pick(h, 1, B);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * T * (double)B * D * 3 * D);
+          DeviceTurn turn(h);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
         if (i == 0 && use_table(h, rt, B)) {
@@ -967,7 +1018,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
             if (gh16) AV_TRY(gemm_tn16(h, w.dgh16_d, nullptr, 3 * D, w.d_hp16[i], nullptr, D, G + p.R, D, 3 * D, D, rt, 1.f, ddyn));
             else
             AV_TRY(gemm_tn_grad(h, w.dgh_d, 3 * D, w.d_hp[i], D, G + p.R, D, 3 * D, D, rt, 1.f, ddyn));
-            AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, w.demb_tgt, D, U, D, 3 * D, 1.f, nullptr, 0, 0, cnt, 1));
+            AV_TRY(gemm(h, false, true, w.dew, 3 * D, P + p.W, D, w.demb_tgt, D, U, D, 3 * D, 1.f, nullptr, 0, 0, cnt, 1, true));
             AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_tgt, id_groups_uid(w.grp_tgt, rt, V), cnt, U, D));
         } else if (g16) {
             const float* x = i == 0 ? w.emb_tgt : w.d_hd[i - 1];
@@ -1052,6 +1103,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
         a.bwd_rs = rs_pick(h, a.njobs, B); a.spec = spec_pick(h, a.njobs, B);
         hook_fence(h);
         { Timed t(h, 2, 2.0 * a.njobs * (Ss - 1) * (double)B * D * 3 * D);
+          DeviceTurn turn(h);
           AV_GRU(gru_backward(st, a, h->persistent != 0)); }
         hook_flush(h);
         const bool table = i == 0 && use_table(h, rs, B);
@@ -1089,7 +1141,7 @@ int backward(avae_ctx* h, Ws& w, int B, int Ss, int St, float b_global)
                 // table-fed layer (use_table): gate gradients summed by id, dE[present] += (sum) W over U rows
                 const int32_t* cnt = id_groups_count(w.grp_src, rs, V); const int U = std::min(V, rs);
                 AV_CHECK(rows_group_sum(st, w.dew, w.src_tm, w.dgi_e, rs, 6 * D, V, w.grp_src));
-                AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, w.demb_src, D, U, D, 6 * D, 1.f, nullptr, 0, 0, cnt, 1));
+                AV_TRY(gemm(h, false, true, w.dew, 6 * D, P + p.W, D, w.demb_src, D, U, D, 6 * D, 1.f, nullptr, 0, 0, cnt, 1, true));
                 AV_CHECK(rows_add_indexed(st, G + h->oE, w.demb_src, id_groups_uid(w.grp_src, rs, V), cnt, U, D));
             } else
             AV_TRY(gemm(h, false, true, w.dgi_e, 6 * D, P + p.W, In, dx, In, rs, In, 6 * D, 1.f, nullptr, 0, 0, nullptr, 0, true));
@@ -1265,6 +1317,7 @@ void avae_destroy(avae_handle h)
     if (h->bfA) (void)hipFree(h->bfA);
     if (h->bfP) (void)hipFree(h->bfP);
     if (h->bfB) (void)hipFree(h->bfB);
+    if (h->lock_fd >= 0) (void)close(h->lock_fd);
     delete h;
 }
 
@@ -1345,6 +1398,8 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "gru_force_slow")) { h->gru_force_slow = value; return 0; }
     if (!strcmp(key, "gru_bf16")) { h->gru_bf16 = value != 0; return 0; }
     if (!strcmp(key, "bwd_rs")) { h->bwd_rs = value; return 0; }
+    if (!strcmp(key, "dyn_split")) { h->dyn_split = value != 0; return 0; }
+    if (!strcmp(key, "shared_device")) { h->shared_device = value != 0; return 0; }
     if (!strcmp(key, "gru_spec")) { h->gru_spec = value; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }

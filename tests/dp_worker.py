@@ -1,6 +1,7 @@
 """worker of tests/test_gpu_dp.py: one data-parallel rank computing on cuda:0, gradients all-reduced over gloo
 (two ranks share the one GPU of the test box; RCCL refuses two ranks on one device, the code path above the
-transport -- bucket hook, side stream, global-count scaling, Adam after the reduce -- is the production one)."""
+transport -- bucket hook, side stream, global-count scaling, Adam after the reduce -- is the production one; because
+a persistent GRU launch needs every CU, the two processes take turns for those launches: option shared_device)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +20,7 @@ def main():
     kw = dict(dim_tgt=int(case['V']), dim_emb=int(case['D']), dim_rep=int(case['R']), rnn_layers=3, seed=0)
     m = VAE('train', **kw)
     m.step = 20000
+    m.set_option('shared_device', 1)      # two processes on ONE GPU: persistent launches take turns (a persistent launch needs every CU)
     dp = DataParallel(m)
     dp.broadcast_params(m.state)
     ids, keep, eps = case['ids'], case['keep'], case['eps']

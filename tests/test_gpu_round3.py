@@ -289,7 +289,7 @@ def test_padding_skipped_in_the_team_kernels_changes_nothing(B, S, dtype):
     else:                                            # bf16 gate gradients: the same values, summed by the GEMMs in the same order
         assert np.array_equal(out[1][0], out[0][0])
     d = float((out[1][2] - out[0][2]).norm() / out[0][2].norm())
-    assert d < (1e-5 if dtype == 'f32' else 3e-5), d      # (bf16: float atomics over bf16-rounded products, 1.09e-5 seen)
+    assert d < (1e-5 if dtype == 'f32' else 1e-4), d      # (bf16: float atomics over bf16-rounded products -- 1.1e-5 ... 3.5e-5 seen from run to run over rounds 3-4; the mode's gradient tolerance against the oracle is 5e-2)
     assert all(np.isfinite(out[1][3]))
     m.close()
 

@@ -247,3 +247,30 @@ def test_configs0_training_driver_over_the_real_text(tmp_path):
     assert all(np.isfinite([r['step_errt'], r['step_loss_gen'], r['step_loss_kld'], r['sentences_per_sec']]).all() for r in recs)
     assert recs[1]['step_loss_gen'] < recs[0]['step_loss_gen'] < np.log(8192.0) + 0.5
     assert (d / 'ckpt' / 'c00.npz').exists()
+
+
+# ------------------------------------------------------------------------------------------ launch shaping that must not change results
+def test_ragged_split_k_and_shared_device_turns_change_only_the_summation_order():
+    """Two round-4 knobs that shape launches only.  dyn_split: on a ragged batch in the compact layout the narrow backward GEMMs over few
+    EXPECTED rows (dho = dlogits E, the decoder's dx, dE of the present ids) split K with float atomics instead of leaving the chip at one
+    workgroup per CU -- the expectation comes from an earlier call's fill and never decides a value: same losses bit for bit, gradients to
+    float-atomic order.  shared_device: persistent launches taken in turn across processes (a lock file and one synchronisation per
+    launch) -- the same kernels in the same order: z, losses and per-token CE bit for bit."""
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    ids = synth.batch(256, 48, 8192, ragged=True, seed=21)
+    m = VAE('train', seed=0, dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    m.set_option('compact', 1)
+    out = {}
+    for key in ((1, 0), (1, 0), (0, 0), (1, 1)):          # (dyn_split, shared_device); the second call has seen the first one's fill
+        m.set_option('dyn_split', key[0]); m.set_option('shared_device', key[1])
+        m.forward_backward(ids, ids, seed=3)
+        out[key] = (m.losses(), m.train_ce(), m.grads.clone(), m.encode(ids))
+    base = out[(0, 0)]
+    for key in ((1, 0), (1, 1)):
+        assert out[key][0] == base[0] and np.array_equal(out[key][1], base[1]) and np.array_equal(out[key][3], base[3])
+        d = float((out[key][2] - base[2]).norm() / base[2].norm())
+        assert d <= 1e-5, (key, d)
+    assert os.path.exists('/tmp/argsim_vae_dev%d.lock' % m.device.index)
+    m.close()
