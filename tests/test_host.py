@@ -277,3 +277,49 @@ def test_bench_quotes_committed_counters_only_for_the_sources_they_were_taken_on
     json.dump({'source_digest': '0' * 16, 'gemm_class': {}}, open(tmp_path / 'profiles' / 'rXX_pmc_summary.json', 'w'))
     pm, why = bench.pmc_summary('rXX')
     assert pm is None and 'other kernel sources' in why
+
+
+REF_POSTS = '/root/reference/docs/results_iac/clustering.csv'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_POSTS), reason="the reference tree (its docs hold the only real corpus) is not on this machine")
+def test_data_prep_iac_on_the_reference_posts(tmp_path):
+    """SURVEY 8f item 3 on REAL text (build container only: the GPU box has no reference tree): the 1 901 cleaned IAC posts of the
+    reference's docs/results_iac/clustering.csv, laid out as fourforums discussion files (post field 3 = text, data_iac.py:18-27), go
+    through prep_iac: an 8192-piece SentencePiece model with the reference's ids (util_sp.py:17-39), train.txt = the DECODE of every
+    post capped to 64 pieces at a sentence boundary (data_iac.py:37-41, util_sp.py:42-63), valid.npy = capped validation posts packed
+    with eos (data_iac.py:43-46).  Checked: piece ids, every training line re-encodes to at most 64 pieces, the rows of valid.npy are the
+    capped encodings, and the committed configs[0] ids (tests/golden/configs0_ids.npz) are what this flow produces for the same posts."""
+    import csv, json
+    from argsim_amd import data_prep, util_sp
+    csv.field_size_limit(1 << 30)
+    with open(REF_POSTS, newline='') as f:
+        posts = [r['post'].replace('\n', ' ').strip() for r in csv.DictReader(f)]
+    posts = [p for p in posts if p]
+    raw = tmp_path / 'discussions'; raw.mkdir()
+    for i in range(0, len(posts), 100):          # 20 "discussions" of 100 posts: [id, side, author, text, annotations, parent, category, time]
+        json.dump([[[j, 's', 'a', posts[j], [], None, 'c', 0] for j in range(i, min(i + 100, len(posts)))], {}, {}], open(raw / ('%04d.json' % i), 'w'))
+    val = tmp_path / 'val.txt'
+    open(val, 'w').write('\n'.join(posts[:50]) + '\n')
+    out = tmp_path / 'data'
+    vocab = data_prep.prep_iac(str(raw), str(val), str(out), cap=64)
+    assert vocab.get_piece_size() == 8192 and (vocab.unk_id(), vocab.eos_id(), vocab.bos_id()) == (0, 1, 2)
+    train = open(out / 'train.txt').read().splitlines()
+    assert len(train) == len(posts)
+    assert all(0 < len(vocab.encode_as_ids(t)) <= 64 for t in train[:300])
+    valid = np.load(out / 'valid.npy')
+    assert valid.shape == (50, 64) and valid.dtype == np.int32
+    for row, p in zip(valid, posts[:50]):
+        ids = util_sp.encode_capped(vocab, util_io_clean(p), cap=64)
+        assert list(row[:len(ids)]) == ids and (row[len(ids):] == 1).all()
+    # the committed configs[0] ids come from the same trainer flags and the same cap on the same posts (make_configs0_golden.py trains on
+    # the posts in csv order, prep_iac on the same order through the sorted discussion files): the same model, the same ids
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'configs0_ids.npz'))['ids']
+    mine = [util_sp.encode_capped(vocab, p, cap=64) for p in posts[:40]]
+    same = sum(list(g[:len(m)]) == m and (g[len(m):] == 1).all() for g, m in zip(gold[:40], mine))
+    assert same >= 38, same          # (clean() of data_iac.py may touch a post the golden script encoded as it stands)
+
+
+def util_io_clean(x):
+    from argsim_amd.util_io import clean
+    return clean(x)
