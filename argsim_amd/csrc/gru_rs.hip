@@ -18,9 +18,10 @@
 // What it costs (measured): every row and step now WRITES 32 partial rows of 512 floats -- 64 KB of unique
 // bytes against the 6 KB of dgh the other form stores once and lets 32 workgroups read from L2.  On a FULL 256 x 64 batch that is
 // 8.2 GB of stores per training step: the kernel becomes store-bandwidth bound (3.7 ms against 3.0 ms; with the stores ablated
-// 2.3 ms).  Where few rows are alive per step -- long ragged chains, small batches -- the volume is small and the shorter
-// dependency chain wins (batch 100 x 512 ragged: 40.0 ms per training step against 43.6).  The host picks the form per call
-// from the fill it expects (model.cpp rs_pick); both forms compute the same sums up to fp32 summation order.
+// 2.3 ms); small FULL batches lose as well (+2..5 %).  Where a workgroup's teams run out of rows at different times -- a ragged batch
+// with a long tail: most steps belong to one or two lone chains -- the volume is small and the shorter dependency chain wins (batch
+// 100 x 512 ragged: 40.0 ms per training step against 43.6).  The host picks the form per call from the fill it expects (model.cpp
+// rs_pick: below 0.40); both forms compute the same sums up to fp32 summation order.
 //
 // Exchange ("the data is the flag", as in gru.hip, with a tag bit instead of a sentinel value so that the buffer can be a
 // ring): a partial tile has exactly one consumer, so the exchange is a ring of TWO slots per 16-row block; the k-th use of a

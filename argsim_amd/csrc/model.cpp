@@ -602,21 +602,24 @@ static double expected_fill(const avae_ctx* h)
     const int32_t real = (int32_t)(uint32_t)(pair & 0xffffffffull), rows = (int32_t)(uint32_t)(pair >> 32);
     return (real > 0 && rows > 0) ? std::min(1.0, (double)real / (double)rows) : 1.0;
 }
-// Which BPTT team kernel a launch of njobs jobs over B rows takes (option bwd_rs = 2): the reduce-scatter form stores 64 KB per live
-// row and step where the other form stores 6 KB, so it pays where few rows are alive -- measured break-even at about 220 live
-// row-chains per step (RAGGED 256 x 64 at fill 0.44: a tie; batch 100 x 512 ragged: -8 % of the step; FULL 256 x 64: +5 %).
-static bool few_rows(const avae_ctx* h, int njobs, int B) { return expected_fill(h) * B * njobs < 200.0; }
+// Which BPTT team kernel a launch takes (option bwd_rs = 2).  The reduce-scatter form stores 64 KB per live row and step where the other
+// form stores 6 KB, and wins only where a workgroup's teams run out of rows at different times so that most steps belong to one or two
+// lone chains -- a ragged batch with a long tail.  Measured: batch 100 x 512 ragged (fill 0.30) -8 % of the step; RAGGED 256 x 64 (fill
+// 0.44) a tie; FULL batches lose at every size (64 x 64 +1.8 %, 128 x 64 +4.7 %, 100 x 512 +2.3 %, 256 x 64 +5 %).  So the fill decides,
+// not the row count.
 static int rs_pick(const avae_ctx* h, int njobs, int B)
 {
+    (void)njobs; (void)B;
     if (h->bwd_rs != 2) return h->bwd_rs;
-    return few_rows(h, njobs, B) ? 1 : 0;
+    return expected_fill(h) < 0.40 ? 1 : 0;
 }
 // the same regime in the exchange of every team kernel (option gru_spec = 2): a consumer's first operand load goes out without a probe
-// round trip in front of it (GruArgs::spec).  With many teams alive the probe is what keeps the texture addresser free.
+// round trip in front of it (GruArgs::spec): RAGGED 256 x 64 (fill 0.44) -1.5 %; forced on, a FULL 100 x 512 batch loses 1 %.
 static int spec_pick(const avae_ctx* h, int njobs, int B)
 {
+    (void)njobs; (void)B;
     if (h->gru_spec != 2) return h->gru_spec;
-    return few_rows(h, njobs, B) ? 1 : 0;
+    return expected_fill(h) < 0.60 ? 1 : 0;
 }
 
 // -------------------------------------------------------------------------------- forward pieces

@@ -87,8 +87,8 @@ def test_reduce_scatter_bptt_equals_the_other_form(B, S, ragged):
 
 
 def test_auto_choice_of_the_bptt_form_follows_the_fill():
-    """bwd_rs = 2 (default): the host takes the reduce-scatter form where few rows are alive per step (expected fill x rows x jobs
-    below the measured break-even) and the other form on full batches; either way the gradients are those of the forced forms."""
+    """bwd_rs = 2 (default): the host takes the reduce-scatter form where the fill it expects is low (a ragged batch with a long tail:
+    below 0.40, the measured break-even) and the other form on fuller batches; either way the gradients are those of the forced forms."""
     from argsim_amd import synth
     from argsim_amd.model import VAE
     V = 8192
