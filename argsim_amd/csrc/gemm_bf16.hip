@@ -581,6 +581,7 @@ hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const 
     int s2 = g.split_k > 1 ? (512 + big_tiles / 2) / big_tiles : 1;
     s2 = std::max(1, std::min(std::min(s2, 16), std::max(1, g.K / (4 * BKH))));      // (more slices: the float atomics dominate)
     if (g.N >= 192 && g.M >= 192 && big_tiles * s2 >= 200) {
+        if (gemm_bf16_p8_ok(g, lda, ldb)) return gemm_bf16_p8(st, A, lda, B, ldb, g, s2);
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds);

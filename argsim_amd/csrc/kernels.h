@@ -29,6 +29,7 @@ struct GemmArgs {
     // weight-gradient GEMMs over the same rows then share ONE round of workgroups at half the K split (half the
     // float-atomic traffic each), two small affines share one launch.  Exact-fp32 kernel only.
     const float* A2; const float* B2; float* C2; const float* bias2;
+    int nt8 = 1;         // bf16 NT form: the phased LDS-DMA kernel (gemm_bf16_p8.hip) where the shape allows; 0: gemm_bf16_nt256_kernel
 };
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
 // same contract on the bf16 matrix cores: every fp32 operand element is split into three bf16 in registers and
@@ -45,6 +46,9 @@ hipError_t cvt_bf16(hipStream_t st, const float* src, int ld, bool transpose, in
                     unsigned short* dst, int ldd);
 // C = alpha * A B^T (+bias)(+C): A [M][lda], B [N][ldb] bf16 k-contiguous; the other fields as in GemmArgs
 hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);
+// the phased 256x256 form of the same contract (gemm_bf16_p8.hip); _ok: K % 64 == 0, N % 4 == 0, aligned C / bias, no device-side K
+bool gemm_bf16_p8_ok(const GemmArgs& g, int lda, int ldb);
+hipError_t gemm_bf16_p8(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g, int s2);
 // C = alpha * A^T B (+C): A [K][lda] (m contiguous), B [K][ldb] (n contiguous) bf16, read with transposing LDS loads -- no
 // transposed copy of either operand (M, N, lda, ldb multiples of 8; split_k > 1: float atomics into C)
 hipError_t gemm_bf16_tn(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);

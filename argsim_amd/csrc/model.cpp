@@ -68,6 +68,7 @@ struct avae_ctx {
     int bf16_act = 1;     // compute_dtype 1: h / h_prev row-major copies written as bf16 by the forward team kernels (the GEMM operands as they stand)
     int bf16_sv = 1;      // compute_dtype 1: saved gates as bf16 where a layer's forward and backward both run the team kernels
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
+    int bf16_nt8 = 1;     // compute_dtype 1: NT GEMMs on the phased LDS-DMA kernel (gemm_bf16_p8.hip) where the shape allows (0: the register-staged 256x256 kernel)
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
     int gru_spec = 2;     // team kernels load a consumer's operand at once, without a probe round trip in front of it: 0 never, 1 always, 2 where few rows are alive per
@@ -379,6 +380,7 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
         AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)N * Kp));
         AV_CHECK(cvt_bf16(h->stream, A, lda, a_mc, a_mc ? K : M, a_mc ? M : K, a16, Kp));
         AV_CHECK(cvt_bf16(h->stream, Bm, ldb, b_nc, b_nc ? K : N, b_nc ? N : K, h->bfB, Kp));
+        g.nt8 = h->bf16_nt8;
         AV_CHECK(gemm_bf16_nt(h->stream, a16, Kp, h->bfB, Kp, g));
         return 0;
     }
@@ -405,6 +407,7 @@ int gemm_bf16_pre(avae_ctx* h, const unsigned short* A16, int lda16, bool a_mc, 
     }
     AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)N * Kp));
     AV_CHECK(cvt_bf16(h->stream, Bm, ldb, b_nc, b_nc ? K : N, b_nc ? N : K, h->bfB, Kp));
+    g.nt8 = h->bf16_nt8;
     AV_CHECK(gemm_bf16_nt(h->stream, Ap, lda_p, h->bfB, Kp, g));
     return 0;
 }
@@ -1404,6 +1407,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "dyn_split")) { h->dyn_split = value != 0; return 0; }
     if (!strcmp(key, "shared_device")) { h->shared_device = value != 0; return 0; }
     if (!strcmp(key, "gru_spec")) { h->gru_spec = value; return 0; }
+    if (!strcmp(key, "bf16_nt8")) { h->bf16_nt8 = value != 0; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
     if (!strcmp(key, "bf16_sv")) { h->bf16_sv = value != 0; return 0; }
