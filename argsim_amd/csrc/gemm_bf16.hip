@@ -556,6 +556,7 @@ hipError_t gemm_bf16_tn(hipStream_t st, const unsigned short* A, int lda, const 
     const int big_tiles = ((g.M + T2 - 1) / T2) * ((g.N + T2 - 1) / T2);
     int s2 = g.split_k > 1 ? (512 + big_tiles / 2) / big_tiles : 1;
     s2 = std::max(1, std::min(std::min(s2, 16), std::max(1, g.K / (4 * BKH))));
+    if (gemm_bf16_p8_tn_ok(g, lda, ldb)) return gemm_bf16_p8_tn(st, A, lda, B, ldb, g, s2);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTnLds);

@@ -29,6 +29,7 @@ struct GemmArgs {
     // weight-gradient GEMMs over the same rows then share ONE round of workgroups at half the K split (half the
     // float-atomic traffic each), two small affines share one launch.  Exact-fp32 kernel only.
     const float* A2; const float* B2; float* C2; const float* bias2;
+    float* slab = nullptr; size_t slab_floats = 0;      // bf16 TN form, K split: workspace for the slices' partial tiles (summed by a reduce pass instead of float atomics)
     int nt8 = 1;         // bf16 NT form: the phased LDS-DMA kernel (gemm_bf16_p8.hip) where the shape allows; 0: gemm_bf16_nt256_kernel
 };
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
@@ -49,6 +50,9 @@ hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const 
 // the phased 256x256 form of the same contract (gemm_bf16_p8.hip); _ok: K % 64 == 0, N % 4 == 0, aligned C / bias, no device-side K
 bool gemm_bf16_p8_ok(const GemmArgs& g, int lda, int ldb);
 hipError_t gemm_bf16_p8(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g, int s2);
+// ... and of gemm_bf16_tn's contract (operands [k][x] row-major, K host- or device-side, any K)
+bool gemm_bf16_p8_tn_ok(const GemmArgs& g, int lda, int ldb);
+hipError_t gemm_bf16_p8_tn(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g, int s2);
 // C = alpha * A^T B (+C): A [K][lda] (m contiguous), B [K][ldb] (n contiguous) bf16, read with transposing LDS loads -- no
 // transposed copy of either operand (M, N, lda, ldb multiples of 8; split_k > 1: float atomics into C)
 hipError_t gemm_bf16_tn(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g);

@@ -95,6 +95,7 @@ struct avae_ctx {
     int timing = 0, timing_on = 0;
     // bf16-operand GEMM mode (compute_dtype = 1): converted operand panels
     unsigned short *bfA = nullptr, *bfB = nullptr; size_t bfA_cap = 0, bfB_cap = 0;
+    float* slab = nullptr; size_t slab_floats = 0;     // bf16 mode: the K slices' partial tiles of the weight-gradient GEMMs (gemm_bf16_p8.hip; 512 tiles of 256 x 256)
     unsigned short* keep_a16 = nullptr;       // one-shot: the next bf16-mode GEMM converts its (k-contiguous) A operand HERE and leaves it for the backward (gemm_raw)
     unsigned short* bfP = nullptr; size_t bfP_cap = 0;     // bf16 mode: (softmax - onehot)/N as written by softmax_ce_kernel, (N,V) bf16
     // (dyn / dyn_max: a GEMM whose M or K is a device-side count -- its FLOPs are scaled by count / static bound at collection)
@@ -434,6 +435,15 @@ int gemm_tn16(avae_ctx* h, const unsigned short* A16, const float* A32, int lda,
         AV_TRY(grow_bf16(h, &h->bfB, &h->bfB_cap, (size_t)K * lb));
         AV_CHECK(cvt_bf16(h->stream, B32, ldb, false, K, N, h->bfB, lb));
         B16 = h->bfB;
+    }
+    g.nt8 = h->bf16_nt8;
+    if (h->bf16_nt8 && s > 1) {
+        if (!h->slab) {
+            const size_t n = (size_t)512 << 16;
+            AV_CHECK(hipMalloc(reinterpret_cast<void**>(&h->slab), n * sizeof(float)));
+            h->slab_floats = n;
+        }
+        g.slab = h->slab; g.slab_floats = h->slab_floats;
     }
     AV_CHECK(gemm_bf16_tn(h->stream, A16, la, B16, lb, g));
     return 0;
@@ -1321,6 +1331,7 @@ void avae_destroy(avae_handle h)
     if (h->counters) (void)hipFree(h->counters);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->bfA) (void)hipFree(h->bfA);
+    if (h->slab) (void)hipFree(h->slab);
     if (h->bfP) (void)hipFree(h->bfP);
     if (h->bfB) (void)hipFree(h->bfB);
     if (h->lock_fd >= 0) (void)close(h->lock_fd);
@@ -1530,6 +1541,12 @@ int avae_debug_gemm(avae_handle h, int a_mc, int b_nc, const float* A, const flo
     if (!h) return 1;
     // split_k == -1 selects the thin (32x128 tile) variant, -3 the skinny form, 1000 + s the 64x64-tile variant with s K slices
     return gemm_raw(h, a_mc != 0, b_nc != 0, A, lda, Bm, ldb, Cm, ldc, M, N, K, alpha, bias, accumulate, split_k < 0 ? 1 : (split_k >= 1000 ? split_k - 1000 : split_k), nullptr, 0, split_k == -3 ? 3 : (split_k < 0 ? 1 : (split_k >= 1000 ? 2 : 0)));
+}
+// test hook: C = A B^T (A (M, K), B (N, K) row-major) over the first *rows rows of A only, rows read on the DEVICE (dyn_kind 1)
+int avae_debug_gemm_dyn(avae_handle h, const float* A, const float* Bm, float* Cm, int M, int N, int K, const int* rows)
+{
+    if (!h) return 1;
+    return gemm_raw(h, false, false, A, K, Bm, K, Cm, N, M, N, K, 1.f, nullptr, 0, 1, rows, 1, 0);
 }
 // test hook: C (M x N) += alpha * A^T B with A (K x M, lda), B (K x N, ldb) fp32 row-major, operands rounded to bf16 row by
 // row and read through the transposing-LDS-load GEMM (gemm_tn16 / gemm_bf16_tn); C must hold the value to add onto

@@ -19,7 +19,12 @@ shapes = [  # name, a_mc, b_nc, M, N, K
     ('enc dX', 0, 1, 131072, 1024, 3072),
     ('dec dX', 0, 1, 132096, 512, 1536),
 ]
-if len(sys.argv) > 1: shapes = [x for x in shapes if x[0].startswith(sys.argv[1])]
+tn_shapes = [  # weight gradients C (M x N) += A^T B over K = tokens rows
+    ('tn dE', 8192, 512, 132096),
+    ('tn enc dW', 3072, 1024, 131072),
+    ('tn dec dW', 1536, 512, 132096),
+]
+if len(sys.argv) > 1: shapes = [x for x in shapes if x[0].startswith(sys.argv[1])]; tn_shapes = [x for x in tn_shapes if x[0].startswith(sys.argv[1])]
 for name, a_mc, b_nc, M, N, K in shapes:
     A = torch.randn((K, M) if a_mc else (M, K), device=dev)
     B = torch.randn((K, N) if b_nc else (N, K), device=dev)
@@ -43,3 +48,24 @@ for name, a_mc, b_nc, M, N, K in shapes:
         res.append('%8.1f us %7.1f TFLOP/s' % (ms * 1e3, 2.0 * M * N * K / ms / 1e9))
     d = float((outs[0] - outs[1]).abs().max()); s = float(outs[0].abs().max())
     print('%-12s M %6d N %5d K %5d | nt256 %s | p8 %s | max diff %.2e of %.1f' % (name, M, N, K, res[0], res[1], d, s), flush=True)
+
+for name, M, N, K in tn_shapes:
+    A = torch.randn((K, M), device=dev); B = torch.randn((K, N), device=dev)
+    res = []; outs = []
+    for form in (0, 1):
+        assert l.avae_set_option(h, b'bf16_nt8', form) == 0
+        Cm = torch.zeros((M, N), device=dev)
+        def run():
+            assert l.avae_debug_gemm_tn16(h, A.data_ptr(), B.data_ptr(), Cm.data_ptr(), M, N, K, M, N, N, 1.0) == 0
+        for _ in range(2): run()
+        torch.cuda.synchronize()
+        outs.append(Cm.clone())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        e0.record()
+        for _ in range(n): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        res.append('%8.1f us %7.1f TFLOP/s' % (ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+    d = float((outs[0] - outs[1]).abs().max()); sc = float(outs[0].abs().max())
+    print('%-12s M %6d N %5d K %6d | tn256 %s | p8 %s | max diff %.2e of %.1f' % (name, M, N, K, res[0], res[1], d, sc), flush=True)

@@ -274,3 +274,51 @@ def test_ragged_split_k_and_shared_device_turns_change_only_the_summation_order(
         assert d <= 1e-5, (key, d)
     assert os.path.exists('/tmp/argsim_vae_dev%d.lock' % m.device.index)
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ phased persistent bf16 NT GEMM (gemm_bf16_p8.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,bias,acc,split,dyn", [
+    (8200, 4104, 512, True, 0, 1, 0),       # 33 x 17 tiles on 256 workgroups: whole tiles (counted epilogue) and edge tiles (drained) follow each other
+    (16384, 1536, 128, False, 0, 1, 0),     # two K tiles per item: every look-ahead crosses into the next item
+    (5000, 768, 1024, True, 1, 1, 0),       # C += : the epilogue reads C
+    (2048, 1024, 8192, True, 0, 5, 0),      # K split into uneven slices (128 K tiles over 5), float atomics, bias added once
+    (9000, 2048, 576, False, 0, 1, 7777),   # device-side row count below M: fewer tiles than the grid was sized for
+    (70000, 512, 1536, True, 0, 1, 0),      # two tile columns: groups of 8 x 2 tiles
+])
+def test_bf16_phased_gemm_matches_the_register_staged_kernel(M, N, K, bias, acc, split, dyn):
+    """compute_dtype 1: the persistent LDS-DMA kernel against float64 products of the same bf16-rounded operands AND against the
+    register-staged 256x256 kernel (option bf16_nt8 = 0) on the same call."""
+    import ctypes as C
+    import torch
+    from argsim_amd.model import VAE
+    m = VAE('train', dtype='bf16', dim_tgt=64, dim_emb=16, dim_rep=8, rnn_layers=1)
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn((M, K), device='cuda', generator=g) * 0.5
+    B = torch.randn((N, K), device='cuda', generator=g) * 0.5
+    bv = torch.randn((N,), device='cuda', generator=g)
+    C0 = torch.randn((M, N), device='cuda', generator=g)
+    rows = dyn if dyn else M
+    m._stream()
+    out = []
+    for form in (1, 0):
+        m.set_option('bf16_nt8', form)
+        Cm = C0.clone() if acc else torch.zeros((M, N), device='cuda')
+        if dyn:
+            cnt = torch.tensor([dyn], dtype=torch.int32, device='cuda')
+            rc = m._l.avae_debug_gemm_dyn(m._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), M, N, K, C.c_void_p(cnt.data_ptr()))
+        else:
+            rc = m._l.avae_debug_gemm(m._h, 0, 0, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()),
+                                      C.c_void_p(bv.data_ptr()) if bias else None, M, N, K, K, K, N, 0.5 if not dyn else 1.0, acc, split)
+        assert rc == 0, m._l.avae_last_error(m._h)
+        torch.cuda.synchronize()
+        out.append(Cm)
+    alpha = 1.0 if dyn else 0.5
+    ref = alpha * (A[:rows].bfloat16().double() @ B.bfloat16().double().t())
+    if bias and not dyn: ref = ref + bv.double()
+    if acc: ref = ref + C0[:rows].double()
+    tol = 2e-4 * max(1.0, float(ref.abs().max()))
+    assert float((out[0][:rows].double() - ref).abs().max()) <= tol
+    assert float((out[0][:rows] - out[1][:rows]).abs().max()) <= tol
+    if dyn: assert float(out[0][rows:].abs().max()) == 0.0          # rows beyond the device-side count are not written
+    m.close()
