@@ -90,6 +90,23 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* p) { return __builti
 #define P8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define P8_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
 
+// The accumulator layout gives lane (fr, fq) columns 4 fq .. 4 fq + 3 of row fr in each of two 16-column tiles (x: columns 0-15, y: 16-31 of
+// the wave's 32): stored as they stand, one instruction writes 16 rows x 64 B -- half lines, 3.0-3.3 TB/s chip-wide on a store-only
+// stream (scripts/micro/store_pattern.hip), and a K = 512 output tile's 256 KB took longer to drain than its MFMAs to run.  Lanes fr and
+// fr ^ 1 trade one register set (quad-permute DPP): the even lane ends up with columns 4 fq.. of rows fr and fr + 1 out of x, the odd lane with
+// those of rows fr - 1 and fr out of y -- s0 goes to row (fr & ~1), s1 to the row below, both at 16-byte chunk (fr & 1) * 4 + fq of the 32
+// columns: one instruction = 8 rows x 128 B, whole lines, 5.0-5.2 TB/s.
+__device__ __forceinline__ void p8_whole_lines(f32x4 x, f32x4 y, int odd, f32x4& s0, f32x4& s1)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float send = odd ? x[e] : y[e];
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, false));      // quad_perm [1, 0, 3, 2]
+        s0[e] = odd ? recv : x[e];
+        s1[e] = odd ? y[e] : recv;
+    }
+}
+
 constexpr bool p8_of_a(int piece) { return piece == AE || piece == AL; }
 struct P8Item { int m0, n0, kt0, nkt, z, tl; };
 
@@ -292,22 +309,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(P8Args g)
             // a K slice's partial tile, whole, into its slab (edge tiles too: what lies beyond M / N is never read back): 32 plain stores,
             // no float atomics -- in this accumulator layout they come as 16 rows x 4 scattered dwords per instruction, far off their rate
             counted = true;
-            float* const t0 = g.slab + ((size_t)(cur.z * tiles + cur.tl) << 16) + (wr * 64 + fr) * kP8Tile + wc * 32 + fq * 4;
+            float* const t0 = g.slab + ((size_t)(cur.z * tiles + cur.tl) << 16) + (wr * 64 + (fr & ~1)) * kP8Tile + wc * 32 + ((fr & 1) * 4 + fq) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<f32x4*>(t0 + ((i >> 2) * 128 + (i & 3) * 16) * kP8Tile + (j >> 1) * 128 + (j & 1) * 16) = g.alpha * acc[i][j];
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 s0, s1;
+                    p8_whole_lines(g.alpha * acc[i][2 * jp], g.alpha * acc[i][2 * jp + 1], fr & 1, s0, s1);
+                    float* const t = t0 + ((i >> 2) * 128 + (i & 3) * 16) * kP8Tile + jp * 128;
+                    *reinterpret_cast<f32x4*>(t) = s0;
+                    *reinterpret_cast<f32x4*>(t + kP8Tile) = s1;
+                }
         } else
         if (counted) {
+            // whole 128-byte lines per store instruction (8 rows x 128 B instead of 16 rows x 64 B: p8_whole_lines)
+            float* const c0 = g.C + (size_t)(cur.m0 + wr * 64 + (fr & ~1)) * g.ldc + cur.n0 + wc * 32 + ((fr & 1) * 4 + fq) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (BIAS) bv = *reinterpret_cast<const f32x4*>(bias_lds + ((j >> 1) * 32 + (j & 1) * 16 + fq * 4) * 4);
-                float* const c0 = g.C + (size_t)rbase * g.ldc + cbase + (j >> 1) * 128 + (j & 1) * 16;
+            for (int jp = 0; jp < 2; ++jp) {
+                f32x4 bv0 = f32x4{0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
+                if constexpr (BIAS) {
+                    bv0 = *reinterpret_cast<const f32x4*>(bias_lds + (jp * 32 + fq * 4) * 4);
+                    bv1 = *reinterpret_cast<const f32x4*>(bias_lds + (jp * 32 + 16 + fq * 4) * 4);
+                }
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<f32x4*>(c0 + (size_t)((i >> 2) * 128 + (i & 3) * 16) * g.ldc) = g.alpha * acc[i][j] + bv;
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 s0, s1;
+                    p8_whole_lines(g.alpha * acc[i][2 * jp] + bv0, g.alpha * acc[i][2 * jp + 1] + bv1, fr & 1, s0, s1);
+                    float* const c = c0 + (size_t)((i >> 2) * 128 + (i & 3) * 16) * g.ldc + jp * 128;
+                    *reinterpret_cast<f32x4*>(c) = s0;
+                    *reinterpret_cast<f32x4*>(c + g.ldc) = s1;
+                }
             }
         } else {
 #pragma unroll
