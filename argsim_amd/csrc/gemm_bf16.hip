@@ -570,11 +570,19 @@ hipError_t gemm_bf16_tn(hipStream_t st, const unsigned short* A, int lda, const 
     return hipGetLastError();
 }
 
+bool gemm_bf16_c16_ok(const GemmArgs& g, int lda, int ldb)
+{
+    const int big_tiles = ((g.M + T2 - 1) / T2) * ((g.N + T2 - 1) / T2);
+    return ((lda | ldb) & 7) == 0 && g.N >= 192 && g.M >= 192 && big_tiles >= 200 && g.split_k <= 1 && !g.bias && !g.accumulate && (g.N & 7) == 0 && (g.ldc & 7) == 0 &&
+           gemm_bf16_p8_ok(g, lda, ldb);
+}
+
 // operands already converted: A [M][lda] bf16, B [N][ldb] bf16, lda/ldb multiples of 8
 hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g)
 {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if ((lda | ldb) & 7) return hipErrorInvalidValue;
+    if (g.c16 && !gemm_bf16_c16_ok(g, lda, ldb)) return hipErrorInvalidValue;      // (only the phased kernel writes the 2-byte panel: the caller asks first)
     GemmBf16Args a{A, B, g.C, g.bias, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, g.accumulate, g.split_k, g.dyn, g.dyn_kind};
     // large tiles where they fill the chip, by themselves or through the K split (a caller's split was sized for 128x128
     // tiles at three workgroups per CU; here one workgroup per CU, so it is re-derived: ~2 rounds of 256 workgroups)

@@ -55,6 +55,7 @@ struct P8Args {
     const unsigned short* A; const unsigned short* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc;
     float alpha; int accumulate, split_k; const int* dyn; int dyn_kind;
+    unsigned short* C16; // NT, whole problem on this kernel: the result as an fp16 panel [M][ldc] instead of fp32 C (GemmArgs::c16)
     float* slab;         // TN, K split: the slices' partial tiles go here as plain stores ([slice][tile][256][256] fp32), p8_slab_reduce_kernel sums them into C
 };
 
@@ -110,15 +111,25 @@ __device__ __forceinline__ void p8_whole_lines(f32x4 x, f32x4 y, int odd, f32x4&
 constexpr bool p8_of_a(int piece) { return piece == AE || piece == AL; }
 struct P8Item { int m0, n0, kt0, nkt, z, tl; };
 
-template <bool BIAS, bool TN>
+// two floats -> one dword of two fp16 (round to nearest even)
+__device__ __forceinline__ unsigned p8_pk_f16(float a, float b)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, h2));
+}
+
+// H16: the output tile leaves as fp16 (P8Args::C16; no bias, no accumulate, no K split): half the bytes of the store drain that a K = 512 tile waits for
+template <bool BIAS, bool TN, bool H16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(P8Args g)
 {
+    static_assert(!H16 || (!BIAS && !TN), "the fp16 panel: plain NT products only");
     extern __shared__ __attribute__((aligned(1024))) unsigned char L[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    constexpr int E = kP8Stores + (BIAS ? 1 : 0);
+    constexpr int E = (H16 ? kP8Stores / 2 : kP8Stores) + (BIAS ? 1 : 0);
 
     int M = g.M, K = g.K;
     if (g.dyn_kind == 1) M = min(M, *g.dyn);
@@ -321,6 +332,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(P8Args g)
                     *reinterpret_cast<f32x4*>(t + kP8Tile) = s1;
                 }
         } else
+        if (H16 && counted) {
+            // fp16: lane (fr, fq) packs its four columns of x (tile 2 jp) and y (tile 2 jp + 1) into two dwords each; v_permlane16_swap trades the odd
+            // 16-lane rows of x with the even rows of y, which leaves fq = 0 / 2 with columns 0-7 / 8-15 and fq = 1 / 3 with columns 16-23 / 24-31 of
+            // the wave's 32: one 16-byte store per lane, 16 rows x 64 B per instruction, 16 instructions per wave and tile
+            unsigned short* const h0 = g.C16 + (size_t)rbase * g.ldc + cur.n0 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 x = g.alpha * acc[i][2 * jp], y = g.alpha * acc[i][2 * jp + 1];
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(p8_pk_f16(x[0], x[1]), p8_pk_f16(y[0], y[1]), false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(p8_pk_f16(x[2], x[3]), p8_pk_f16(y[2], y[3]), false, false);
+                    *reinterpret_cast<u32x4v*>(h0 + (size_t)((i >> 2) * 128 + (i & 3) * 16) * g.ldc + jp * 128) = u32x4v{r0[0], r1[0], r0[1], r1[1]};
+                }
+        } else if (H16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cbase + (j >> 1) * 128 + (j & 1) * 16;
+                if (col >= g.N) continue;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = rbase + (i >> 2) * 128 + (i & 3) * 16;
+                    if (row >= M) continue;
+                    const f32x4 val = g.alpha * acc[i][j];
+                    *reinterpret_cast<u32x2*>(g.C16 + (size_t)row * g.ldc + col) = u32x2{p8_pk_f16(val[0], val[1]), p8_pk_f16(val[2], val[3])};
+                }
+            }
+            P8_WAIT(0);
+        } else
         if (counted) {
             // whole 128-byte lines per store instruction (8 rows x 128 B instead of 16 rows x 64 B: p8_whole_lines)
             float* const c0 = g.C + (size_t)(cur.m0 + wr * 64 + (fr & ~1)) * g.ldc + cur.n0 + wc * 32 + ((fr & 1) * 4 + fq) * 4;
@@ -421,6 +461,7 @@ static hipError_t p8_attrs()
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
     if (e == hipSuccess) done = true;
     return e;
 }
@@ -428,7 +469,8 @@ static hipError_t p8_attrs()
 // s2: the K split (>= 1) as gemm_bf16_nt derived it; the caller's g.split_k > 1 says C holds the value to add onto
 hipError_t gemm_bf16_p8(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g, int s2)
 {
-    P8Args a{A, B, g.C, g.bias, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, g.accumulate, s2, g.dyn, g.dyn_kind, nullptr};
+    P8Args a{A, B, g.C, g.bias, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, g.accumulate, s2, g.dyn, g.dyn_kind, g.c16, nullptr};
+    if (g.c16 && (g.bias || g.accumulate || g.split_k > 1 || s2 > 1)) return hipErrorInvalidValue;
     if (g.split_k > 1 && s2 == 1) a.accumulate = 1;       // the caller's slices were going to ADD into C
     const int nkt = g.K / kP8K;
     if (2 * s2 > nkt) a.split_k = s2 = std::max(1, nkt / 2);       // (every slice holds two K tiles or more)
@@ -436,7 +478,8 @@ hipError_t gemm_bf16_p8(hipStream_t st, const unsigned short* A, int lda, const 
     if (e != hipSuccess) return e;
     const int tiles = ((g.M + kP8Tile - 1) / kP8Tile) * ((g.N + kP8Tile - 1) / kP8Tile);
     const int grid = std::min(tiles * s2, 256);
-    if (g.bias) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false>), dim3(grid), dim3(512), kP8Lds, st, a);
+    if (g.c16) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, true>), dim3(grid), dim3(512), kP8Lds, st, a);
+    else if (g.bias) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false>), dim3(grid), dim3(512), kP8Lds, st, a);
     else hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false>), dim3(grid), dim3(512), kP8Lds, st, a);
     return hipGetLastError();
 }
@@ -462,7 +505,7 @@ hipError_t gemm_bf16_p8_tn(hipStream_t st, const unsigned short* A, int lda, con
     // (a caller's split says C holds the value to add onto -- also when the device shrinks the split to one slice)
     const int add = g.accumulate || g.split_k > 1;
     const bool use_slab = s2 > 1 && g.slab && (size_t)tiles * s2 * (kP8Tile * kP8Tile) <= g.slab_floats;
-    P8Args a{A, B, g.C, nullptr, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, add, s2, g.dyn, g.dyn_kind, use_slab ? g.slab : nullptr};
+    P8Args a{A, B, g.C, nullptr, g.M, g.N, g.K, lda, ldb, g.ldc, g.alpha, add, s2, g.dyn, g.dyn_kind, nullptr, use_slab ? g.slab : nullptr};
     hipError_t e = p8_attrs();
     if (e != hipSuccess) return e;
     const int grid = std::min(tiles * s2, 256);

@@ -30,6 +30,8 @@ struct GemmArgs {
     // float-atomic traffic each), two small affines share one launch.  Exact-fp32 kernel only.
     const float* A2; const float* B2; float* C2; const float* bias2;
     float* slab = nullptr; size_t slab_floats = 0;      // bf16 TN form, K split: workspace for the slices' partial tiles (summed by a reduce pass instead of float atomics)
+    unsigned short* c16 = nullptr;      // bf16 NT form, phased kernel only (gemm_bf16_c16_ok): the result goes HERE as an fp16 panel [M][ldc] INSTEAD of fp32 C (the logits of a
+                                        // training step: softmax_ce reads the 2-byte panel and turns it into the bf16 gradient in place); no bias, no accumulate, no K split
     int nt8 = 1;         // bf16 NT form: the phased LDS-DMA kernel (gemm_bf16_p8.hip) where the shape allows; 0: gemm_bf16_nt256_kernel
 };
 hipError_t gemm_f32(hipStream_t st, bool a_mc, bool b_nc, const GemmArgs& g);
@@ -50,6 +52,8 @@ hipError_t gemm_bf16_nt(hipStream_t st, const unsigned short* A, int lda, const 
 // the phased 256x256 form of the same contract (gemm_bf16_p8.hip); _ok: K % 64 == 0, N % 4 == 0, aligned C / bias, no device-side K
 bool gemm_bf16_p8_ok(const GemmArgs& g, int lda, int ldb);
 hipError_t gemm_bf16_p8(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g, int s2);
+// would gemm_bf16_nt run this problem on the phased kernel (the only one that writes GemmArgs::c16)?
+bool gemm_bf16_c16_ok(const GemmArgs& g, int lda, int ldb);
 // ... and of gemm_bf16_tn's contract (operands [k][x] row-major, K host- or device-side, any K)
 bool gemm_bf16_p8_tn_ok(const GemmArgs& g, int lda, int ldb);
 hipError_t gemm_bf16_p8_tn(hipStream_t st, const unsigned short* A, int lda, const unsigned short* B, int ldb, const GemmArgs& g, int s2);
@@ -220,6 +224,7 @@ struct CeArgs {
     float* loss_samp; float* errt_samp; int32_t* pred;   // (N) optional
     float* loss_acc;          // [0] += sum loss_samp
     unsigned short* grad16;   // optional (N,V) bf16: with write_grad the gradient goes HERE (the bf16 GEMM's operand panel) and the logits stay
+    int logits16;             // the logits are the fp16 panel the GEMM left IN grad16 (GemmArgs::c16): read from there, overwritten in place by the bf16 gradient
 };
 hipError_t softmax_ce(hipStream_t st, const CeArgs& a);
 // pred[i] = argmax_j logits[i, j]  (first max), rows < n

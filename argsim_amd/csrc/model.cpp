@@ -68,6 +68,7 @@ struct avae_ctx {
     int bf16_act = 1;     // compute_dtype 1: h / h_prev row-major copies written as bf16 by the forward team kernels (the GEMM operands as they stand)
     int bf16_sv = 1;      // compute_dtype 1: saved gates as bf16 where a layer's forward and backward both run the team kernels
     int bf16_tn = 1;      // compute_dtype 1: the BPTT team kernels write the gate gradients as bf16 and the weight-gradient GEMMs read row-major bf16 operands through transposing LDS loads (gemm_bf16_tn): no transposed copies
+    int logits16 = 1;     // compute_dtype 1, training forward: the logits leave the phased GEMM as an fp16 panel that softmax_ce turns into the bf16 gradient in place (no fp32 logits)
     int bf16_nt8 = 1;     // compute_dtype 1: NT GEMMs on the phased LDS-DMA kernel (gemm_bf16_p8.hip) where the shape allows (0: the register-staged 256x256 kernel)
     int bf16_direct = 0;  // (measured at configs[2]: 50.2 ms with it, 43.3 ms with the conversion passes + 256x256 NT kernel: off)
     //  compute_dtype 1: GEMMs read their fp32 operands directly and round to bf16 while staging (0: conversion passes + NT kernel)
@@ -357,7 +358,7 @@ struct Pair { const float* A; const float* B; float* C; const float* bias; };
 
 int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
              int M, int N, int K, float alpha, const float* bias, int accumulate, int split_k, const int* dyn, int dyn_kind,
-             int thin = 0, const Pair* pair = nullptr)
+             int thin = 0, const Pair* pair = nullptr, unsigned short* c16 = nullptr)
 {
     if (pair && h->cfg.compute_dtype != 0) {     // the other GEMM kernels take one problem per launch
         AV_TRY(gemm_raw(h, a_mc, b_nc, A, lda, Bm, ldb, C, ldc, M, N, K, alpha, bias, accumulate, split_k, dyn, dyn_kind, thin));
@@ -382,9 +383,11 @@ int gemm_raw(avae_ctx* h, bool a_mc, bool b_nc, const float* A, int lda, const f
         AV_CHECK(cvt_bf16(h->stream, A, lda, a_mc, a_mc ? K : M, a_mc ? M : K, a16, Kp));
         AV_CHECK(cvt_bf16(h->stream, Bm, ldb, b_nc, b_nc ? K : N, b_nc ? N : K, h->bfB, Kp));
         g.nt8 = h->bf16_nt8;
+        g.c16 = c16;
         AV_CHECK(gemm_bf16_nt(h->stream, a16, Kp, h->bfB, Kp, g));
         return 0;
     }
+    if (c16) return fail(h, "the fp16 output panel exists in compute_dtype 1 only");
     // compute_dtype 2: fp32 operands split into 3 x bf16 on the fly (6 partial products, fp32-accurate); thin
     // row panels (a few rows, little work) stay on the exact-fp32 kernel's 32x128 tiles
     if (h->cfg.compute_dtype == 2 && !thin) AV_CHECK(gemm_f32s(h->stream, a_mc, b_nc, g));
@@ -921,14 +924,21 @@ int forward(avae_ctx* h, Ws& w, const int32_t* src, const int32_t* tgt, int B, i
     }
     AV_CHECK(rows_gather(h->stream, w.hc, w.d_hd[L - 1], w.cidx, w.ntok, rt, D, w.compact_d ? w.map_tgt : nullptr));
     AV_TRY(gemm(h, false, true, w.hc, D, h->P + h->oKout, D, w.ho, D, rt, D, D, 1.f, h->P + h->oBout, 0, 0, w.ntok, 1));
-    AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 0, w.ntok, 1));
     CeArgs c{};
     c.logits = w.logits; c.gold = w.gold; c.cidx = w.cidx; c.n_dev = w.ntok; c.n_max = rt; c.V = V;
     c.write_grad = train ? 1 : 0; c.inv_n = inv_n;
     if (train && h->cfg.compute_dtype == 1 && (V & 7) == 0) {      // bf16 mode: the gradient is written as the backward GEMMs' bf16 operand
         AV_TRY(grow_bf16(h, &h->bfP, &h->bfP_cap, (size_t)rt * V));
         c.grad16 = h->bfP;
+        // ... and where the phased GEMM takes the whole product, the logits themselves go THERE as fp16 (2^-12 relative, finer than the bf16
+        // gradient they become): no fp32 logits are written or read -- 4.3 GB of 10.8 GB at configs[2]
+        GemmArgs probe{nullptr, nullptr, nullptr, nullptr, rt, V, D, D, D, V, 1.f, 0, 1, w.ntok, 1, 0, 0, nullptr, nullptr, nullptr, nullptr};
+        probe.nt8 = h->bf16_nt8;
+        if (h->logits16 && !h->bf16_direct && (D & 7) == 0 && gemm_bf16_c16_ok(probe, D, D)) c.logits16 = 1;
     }
+    if (c.logits16) AV_TRY(gemm_raw(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 1, w.ntok, 1, 0, nullptr, h->bfP));
+    else
+    AV_TRY(gemm(h, false, false, w.ho, D, h->P + h->oE, D, w.logits, V, rt, V, D, 1.f / sqrtf((float)D), nullptr, 0, 0, w.ntok, 1));
     c.loss_samp = w.loss_samp; c.errt_samp = w.errt_samp; c.pred = w.pred; c.loss_acc = nullptr;      // (the scalar is summed from loss_samp in a fixed order: finalize_losses)
     AV_CHECK(softmax_ce(h->stream, c));
     float beta = h->cfg.kl_beta;
@@ -1419,6 +1429,7 @@ int avae_set_option(avae_handle h, const char* key, int value)
     if (!strcmp(key, "shared_device")) { h->shared_device = value != 0; return 0; }
     if (!strcmp(key, "gru_spec")) { h->gru_spec = value; return 0; }
     if (!strcmp(key, "bf16_nt8")) { h->bf16_nt8 = value != 0; return 0; }
+    if (!strcmp(key, "logits16")) { h->logits16 = value != 0; return 0; }
     if (!strcmp(key, "bf16_direct")) { h->bf16_direct = value != 0; return 0; }
     if (!strcmp(key, "bf16_tn")) { h->bf16_tn = value != 0; return 0; }
     if (!strcmp(key, "bf16_sv")) { h->bf16_sv = value != 0; return 0; }
@@ -1547,6 +1558,17 @@ int avae_debug_gemm_dyn(avae_handle h, const float* A, const float* Bm, float* C
 {
     if (!h) return 1;
     return gemm_raw(h, false, false, A, K, Bm, K, Cm, N, M, N, K, 1.f, nullptr, 0, 1, rows, 1, 0);
+}
+// test hook (compute_dtype 1): the fp16 output panel of the phased NT GEMM, C16 (M x N) = fp16(alpha * A B^T) over the first *rows rows (rows == nullptr: all);
+// returns 3 where the phased kernel does not take the shape
+int avae_debug_gemm_c16(avae_handle h, const float* A, const float* Bm, unsigned short* C16, int M, int N, int K, float alpha, const int* rows)
+{
+    if (!h) return 1;
+    if (h->cfg.compute_dtype != 1 || (K & 7)) return 3;
+    GemmArgs probe{nullptr, nullptr, nullptr, nullptr, M, N, K, K, K, N, alpha, 0, 1, rows, rows ? 1 : 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    probe.nt8 = h->bf16_nt8;
+    if (!gemm_bf16_c16_ok(probe, K, K)) return 3;
+    return gemm_raw(h, false, false, A, K, Bm, K, nullptr, N, M, N, K, alpha, nullptr, 0, 1, rows, rows ? 1 : 0, 0, nullptr, C16);
 }
 // test hook: C (M x N) += alpha * A^T B with A (K x M, lda), B (K x N, ldb) fp32 row-major, operands rounded to bf16 row by
 // row and read through the transposing-LDS-load GEMM (gemm_tn16 / gemm_bf16_tn); C must hold the value to add onto

@@ -768,6 +768,12 @@ hipError_t latent_bwd(hipStream_t st, const float* dz, const float* mu, const fl
 // per element -- and sums, pass C writes kept * scale / sum - onehot * scale.  exp2 of a non-positive argument on the hardware
 // unit is accurate to 1 ulp; the loss uses m + log(sum).
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float4 half4_to_float4(uint2 v)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 lo = __builtin_bit_cast(h2, v.x), hi = __builtin_bit_cast(h2, v.y);
+    return make_float4((float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]);
+}
 __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(CeArgs a)
 {
     __shared__ float s_m[4], s_s[4]; __shared__ int s_bi[4];
@@ -779,14 +785,17 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(CeArgs a)
     __syncthreads();
     for (int row = blockIdx.x; row < n; row += gridDim.x) {
         float* x = a.logits + (size_t)row * a.V;
+        const _Float16* x16 = reinterpret_cast<const _Float16*>(a.grad16) + (size_t)row * a.V;      // logits16: the row as the GEMM left it, fp16, where the gradient goes
         const int label = a.gold[a.cidx[row]];
         float4 keep[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int c = tid * 4 + 1024 * q;
+            if (a.logits16) keep[q] = c < a.V ? half4_to_float4(*reinterpret_cast<const uint2*>(x16 + c)) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            else
             keep[q] = c < a.V ? *reinterpret_cast<const float4*>(x + c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         }
-        const float xl = x[label];                       // (before anything overwrites the row)
+        const float xl = a.logits16 ? (float)x16[label] : x[label];                       // (before anything overwrites the row)
         // pass A: maximum and its first position
         float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
@@ -850,6 +859,101 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(CeArgs a)
     if (tid == 0 && a.loss_acc) atomicAdd(a.loss_acc, s_acc);
 }
 
+// logits16 (bf16 mode, V <= 8192, V % 8 == 0): the row is the fp16 panel the phased GEMM left where the bf16 gradient goes.  Half the bytes per row
+// means half the loads in flight per workgroup, and the plain one-row-at-a-time form above turned latency bound on it (1.30 ms against 1.21 ms on
+// the 4-byte logits at configs[2]): here a thread moves 16 bytes per access, and the NEXT row's panel and label are fetched as soon as this row's
+// values have left the staging registers -- the three reductions and barriers of a row run under the next row's loads.  The label's logit comes
+// from the owning thread's registers (through LDS), not from a second global read.
+__global__ __launch_bounds__(256) void softmax_ce_h16_kernel(CeArgs a)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    __shared__ float s_m[4], s_s[4], s_xl; __shared__ int s_bi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(a.n_max, *a.n_dev);
+    const float scale = a.inv_n > 0.f ? a.inv_n : 1.f / (float)max(n, 1);
+    uint4 raw[4]; int label = 0;
+    auto fetch = [&](int row) __attribute__((always_inline)) {
+        const uint4* p = reinterpret_cast<const uint4*>(a.grad16 + (size_t)row * a.V);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid * 8 + 2048 * q;
+            raw[q] = c < a.V ? p[c >> 3] : make_uint4(0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u);      // (-inf, -inf)
+        }
+        label = a.gold[a.cidx[row]];
+    };
+    int row = blockIdx.x;
+    if (row < n) fetch(row);
+    for (; row < n; row += gridDim.x) {
+        float e[32];
+        const int lab = label;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned w[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const h2 v = __builtin_bit_cast(h2, w[k]); e[q * 8 + 2 * k] = (float)v[0]; e[q * 8 + 2 * k + 1] = (float)v[1]; }
+        }
+        if (row + (int)gridDim.x < n) fetch(row + gridDim.x);
+        // pass A: maximum and its first position
+        float bv = -INFINITY; int bi = 0x7fffffff; float xl = 0.f; bool mine = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = tid * 8 + 2048 * q + k;
+                if (e[q * 8 + k] > bv) { bv = e[q * 8 + k]; bi = c; }
+                if (c == lab) { xl = e[q * 8 + k]; mine = true; }
+            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_down(bv, o, 64); const int oi = __shfl_down(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();                                 // (s_* of the previous row have been read)
+        if (lane == 0) { s_m[wave] = bv; s_bi[wave] = bi; }
+        if (mine) s_xl = xl;
+        __syncthreads();
+        bv = s_m[0]; bi = s_bi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (s_m[w] > bv || (s_m[w] == bv && s_bi[w] < bi)) { bv = s_m[w]; bi = s_bi[w]; }
+        const float m = bv;
+        // pass B: one exponential per element, kept
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { e[q * 8 + k] = exp_fast(e[q * 8 + k] - m); t += e[q * 8 + k]; }
+            s += t;
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) s_s[wave] = s;
+        __syncthreads();
+        s = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+        if (tid == 0) {
+            const float loss = m + logf(s) - s_xl;
+            if (a.loss_samp) a.loss_samp[row] = loss;
+            if (a.errt_samp) a.errt_samp[row] = (lab != bi) ? 1.f : 0.f;
+            if (a.pred) a.pred[row] = bi;
+        }
+        // pass C: (softmax - onehot) * scale as bf16 (RNE), over the panel
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const float g = scale / s;
+        uint4* const out = reinterpret_cast<uint4*>(a.grad16 + (size_t)row * a.V);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid * 8 + 2048 * q;
+            if (c >= a.V) break;
+            unsigned pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f2 v = {e[q * 8 + 2 * k] * g - ((c + 2 * k) == lab ? scale : 0.f), e[q * 8 + 2 * k + 1] * g - ((c + 2 * k + 1) == lab ? scale : 0.f)};
+                pk[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+            }
+            out[c >> 3] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+}
+
 // the streaming form for V > 8192 (row re-read for the gradient pass; online max / sum-exp)
 __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
 {
@@ -862,10 +966,11 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
     __syncthreads();
     for (int row = blockIdx.x; row < n; row += gridDim.x) {
         float* x = a.logits + (size_t)row * a.V;
+        const _Float16* x16 = reinterpret_cast<const _Float16*>(a.grad16) + (size_t)row * a.V;      // (logits16, see the register form)
         const int label = a.gold[a.cidx[row]];
         float m = -INFINITY, s = 0.f, bv = -INFINITY; int bi = 0x7fffffff;
         for (int c = tid * 4; c < a.V; c += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(x + c);
+            const float4 v = a.logits16 ? half4_to_float4(*reinterpret_cast<const uint2*>(x16 + c)) : *reinterpret_cast<const float4*>(x + c);
             float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -896,7 +1001,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
         }
         const float lse = m + logf(s);
         if (tid == 0) {
-            float loss = lse - x[label];
+            float loss = lse - (a.logits16 ? (float)x16[label] : x[label]);
             if (a.loss_samp) a.loss_samp[row] = loss;
             if (a.errt_samp) a.errt_samp[row] = (label != bi) ? 1.f : 0.f;
             if (a.pred) a.pred[row] = bi;
@@ -905,7 +1010,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(CeArgs a)
         if (a.write_grad) {
             __syncthreads();     // x[label] read before overwrite
             for (int c = tid * 4; c < a.V; c += 1024) {
-                const float4 v = *reinterpret_cast<const float4*>(x + c);
+                const float4 v = a.logits16 ? half4_to_float4(*reinterpret_cast<const uint2*>(x16 + c)) : *reinterpret_cast<const float4*>(x + c);
                 float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] = (expf(e[k] - lse) - ((c + k) == label ? 1.f : 0.f)) * scale;
@@ -927,7 +1032,9 @@ hipError_t softmax_ce(hipStream_t st, const CeArgs& a)
 {
     if (a.n_max <= 0) return hipSuccess;
     if (a.V & 3) return hipErrorInvalidValue;
-    if (a.V <= 8192) hipLaunchKernelGGL(softmax_ce_reg_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    if (a.logits16 && (!a.grad16 || !a.write_grad)) return hipErrorInvalidValue;      // (the fp16 panel is read where the bf16 gradient is written)
+    if (a.logits16 && a.V <= 8192 && (a.V & 7) == 0 && !a.loss_acc) hipLaunchKernelGGL(softmax_ce_h16_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
+    else if (a.V <= 8192) hipLaunchKernelGGL(softmax_ce_reg_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
     else             hipLaunchKernelGGL(softmax_ce_kernel, dim3(min(a.n_max, 8192)), dim3(256), 0, st, a);
     return hipGetLastError();
 }

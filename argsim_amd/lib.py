@@ -68,6 +68,7 @@ SIGNATURES = {
     'avae_set_option': (C.c_int, [_P, C.c_char_p, C.c_int]),
     'avae_debug_gemm': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P] + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int]),
     'avae_debug_gemm_dyn': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    'avae_debug_gemm_c16': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     'avae_debug_gemm_tn16': (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 6 + [C.c_float]),
     'avae_timing_collect': (C.c_int, [_P, C.POINTER(C.c_double)]),
     'avae_debug_timing': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),

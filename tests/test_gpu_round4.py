@@ -322,3 +322,66 @@ def test_bf16_phased_gemm_matches_the_register_staged_kernel(M, N, K, bias, acc,
     assert float((out[0][:rows] - out[1][:rows]).abs().max()) <= tol
     if dyn: assert float(out[0][rows:].abs().max()) == 0.0          # rows beyond the device-side count are not written
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ fp16 logits panel of the training forward (bf16 mode)
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,dyn", [
+    (8200, 8192, 512, 0),         # 33 x 32 tiles: whole tiles (16 counted stores per wave) and the edge tile row (8-byte predicated stores)
+    (16384, 4096, 128, 0),        # two K tiles per item
+    (9000, 8192, 576, 7777),      # device-side row count below M: rows beyond it are not written
+])
+def test_bf16_phased_gemm_fp16_panel_is_the_fp32_result_rounded_once(M, N, K, dyn):
+    """GemmArgs::c16 (gemm_bf16_p8.hip, H16): the same accumulators as the fp32-output kernel, rounded to fp16 (nearest even) in the epilogue
+    and stored as one 2-byte panel -- bit for bit torch's .half() of the fp32 output, over exactly the rows the device-side count names."""
+    import ctypes as C
+    import torch
+    from argsim_amd.model import VAE
+    m = VAE('train', dtype='bf16', dim_tgt=64, dim_emb=16, dim_rep=8, rnn_layers=1)
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn((M, K), device='cuda', generator=g) * 0.5
+    B = torch.randn((N, K), device='cuda', generator=g) * 0.5
+    m._stream()
+    rows = dyn if dyn else M
+    cnt = torch.tensor([rows], dtype=torch.int32, device='cuda')
+    C32 = torch.zeros((M, N), device='cuda')
+    if dyn:
+        rc = m._l.avae_debug_gemm_dyn(m._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(C32.data_ptr()), M, N, K, C.c_void_p(cnt.data_ptr()))
+    else:
+        rc = m._l.avae_debug_gemm(m._h, 0, 0, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(C32.data_ptr()), None, M, N, K, K, K, N, 1.0, 0, 1)
+    assert rc == 0, m._l.avae_last_error(m._h)
+    C16 = torch.full((M, N), 7.0, dtype=torch.float16, device='cuda')
+    rc = m._l.avae_debug_gemm_c16(m._h, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(C16.data_ptr()), M, N, K, 1.0, C.c_void_p(cnt.data_ptr()) if dyn else None)
+    assert rc == 0, m._l.avae_last_error(m._h)
+    torch.cuda.synchronize()
+    assert torch.equal(C16[:rows], C32[:rows].half())
+    if dyn: assert bool((C16[rows:] == 7.0).all())
+    ref = A[:rows].bfloat16().double() @ B.bfloat16().double().t()
+    assert float((C16[:rows].double() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+    m.close()
+
+
+@pytest.mark.gpu
+def test_fp16_logits_panel_changes_the_training_step_by_less_than_the_bf16_gradient_rounding():
+    """compute_dtype 1, training forward (option logits16, default on): the logits leave the phased GEMM as an fp16 panel and softmax_ce turns
+    that panel into the bf16 gradient (softmax - onehot)/N in place; no fp32 logits exist.  Against logits16 = 0 on the same batch: z bit for
+    bit (the encoder does not see it), loss and per-token CE to fp16 accuracy of the logits (2^-12 relative on |logit| <~ 10), gradients well
+    inside the bf16 mode's own tolerance (the gradient panel itself carries 2^-9)."""
+    import numpy as np
+    from argsim_amd import synth
+    from argsim_amd.model import VAE
+    ids = synth.batch(64, 64, 8192, ragged=True, seed=5)
+    m = VAE('train', seed=0, dtype='bf16', dim_tgt=8192, dim_emb=512, dim_rep=128, rnn_layers=3)
+    m.step = 20000
+    out = {}
+    for v in (1, 0):
+        m.set_option('logits16', v)
+        m.forward_backward(ids, ids, seed=3)
+        out[v] = (m.losses(), m.train_ce().copy(), m.grads.clone(), m.encode(ids))
+    assert np.array_equal(out[1][3], out[0][3])
+    assert abs(out[1][0][0] - out[0][0][0]) <= 2e-4 * abs(out[0][0][0]), (out[1][0], out[0][0])
+    assert float(np.abs(out[1][1] - out[0][1]).max()) <= 2e-2
+    assert float(np.abs(out[1][1] - out[0][1]).mean()) <= 2e-3
+    d = float((out[1][2] - out[0][2]).norm() / out[0][2].norm())
+    assert d <= 1e-2, d
+    m.close()
