@@ -220,20 +220,27 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void gemm_f32_kernel(GemmArgs g)
         __syncthreads();
     }
     for (int k0 = kb; k0 < ke; k0 += BK) {
+        // The next K tile's loads go out BEFORE the barrier that publishes this one (the staging registers are free as soon as the LDS
+        // writes have been issued): the barrier wait is time the loads are already in flight -- the load latency is what a K = 512 tile
+        // of the persistent form was exposed to (ablation, gpurun_out/s2_f32_abl.log: no loads +9 %; early issue +2..6 % on the NT shapes).
+        auto next_loads = [&]() __attribute__((always_inline)) {
+            if (k0 + BK < ke) {
+                if (FAST) { const int it = (k0 - kb) / BK + 1; fa.load(ra, it); fb.load(rb, it); }
+                else {
+                    load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
+                    load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
+                }
+            }
+        };
         if (!DB) {
             store_tile<A_MC, BM>(As, ra, tid);
             store_tile<B_NC, BN>(Bs, rb, tid);
+            next_loads();
             __syncthreads();
-        }
-        if (k0 + BK < ke) {
-            if (FAST) {
-                const int it = (k0 - kb) / BK + 1;
-                fa.load(ra, it); fb.load(rb, it);
-            } else {
-                load_tile<A_MC, BM>(ra, g.A, g.lda, m0, M, k0 + BK, ke, tid);
-                load_tile<B_NC, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, ke, tid);
-            }
-        }
+        } else next_loads();
+        // the waves inside their MFMA burst issue ahead of the co-resident workgroups' staging phases (address arithmetic, LDS writes, the
+        // loads' issue): +1-3 % on every shape of the step (gpurun_out/s2_f32_prio2.log); a static priority per workgroup measured nothing
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float a[TM][4], b[TN][4];
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void gemm_f32_kernel(GemmArgs g)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (DB) {
             // the other stage: its readers passed the barrier that ended the previous K tile
             As = (As == smem) ? smem + kStage : smem;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_persist_kernel(GemmArgs g)
         for (int k0 = 0; k0 < K; k0 += BK) {
             store_tile<A_MC, BM>(As, ra, tid);
             store_tile<B_NC, BN>(Bs, rb, tid);
-            __syncthreads();
+            // (the next loads ahead of the barrier: see gemm_f32_kernel)
             if (k0 + BK < K) {
                 if (FAST) { const int it = k0 / BK + 1; fa.load(ra, it); fb.load(rb, it); }
                 else {
@@ -349,6 +357,8 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_persist_kernel(GemmArgs g)
             } else if (more) {
                 first_tile(bid + per_xcd);                    // the next output tile's first K tile, behind these MFMAs
             }
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(1);                    // (see gemm_f32_kernel)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 float a[TM][4], b[TN][4];
@@ -380,6 +390,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_persist_kernel(GemmArgs g)
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
         epilogue<TM, TN, WN>(g, acc, M, m0, n0, BM, BN, wm, wn, h, l31, false, g.bias != nullptr);
