@@ -284,10 +284,11 @@ def main():
             # + summarize_profile.py; FETCH_SIZE doubled per the gfx950 rule): not a measurement of this run, and quoted only while
             # the kernel sources are the ones the passes were taken on
             pm, why = pmc_summary('%s%s' % (PMC_TAG, '' if A.dtype == 'f32' else '_' + A.dtype))
-            if pm and name == 'gemm':
-                traffic = pm['gemm_class']['hbm_bytes_per_dispatch']
-                mfma_busy = pm['gemm_class'].get('mfma_busy')
-            peak = PEAK_F32_MFMA if (A.dtype == 'f32' or name != 'gemm') else (PEAK_BF16_MFMA if A.dtype == 'bf16' else PEAK_BF16_MFMA / 6.0)
+            if pm and (name + '_class') in pm:
+                traffic = pm[name + '_class']['hbm_bytes_per_dispatch']
+                mfma_busy = pm[name + '_class'].get('mfma_busy')
+            # (the matrix instruction the class runs on: fp32 MFMA; bf16 mode: bf16 MFMA in the GEMMs AND the recurrence; f32s: six bf16 products per fp32 one in the GEMMs only)
+            peak = PEAK_F32_MFMA if A.dtype == 'f32' else (PEAK_BF16_MFMA if A.dtype == 'bf16' else (PEAK_BF16_MFMA / 6.0 if name == 'gemm' else PEAK_F32_MFMA))
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
                                "traffic_unit": ("HBM bytes per launch, from the committed PMC passes %s of these sources (not measured by this run)" % pmc_file) if pm else why,
